@@ -1,0 +1,217 @@
+/*
+ * libmi355conv — C ABI of the MI355X (gfx950) conv-net hot path.
+ *
+ * The reference (bababyVN/medical-image-segmentation-and-classification) is pure
+ * Python/PyTorch and has no FFI of its own: its boundary for this path is the
+ * torch.nn leaf-op API called from models/ and utils/helpers.py::train.  Each
+ * entry point below therefore cites the reference call site whose ATen/cuDNN
+ * kernel it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - all tensors are device pointers owned by the caller (PyTorch's caching
+ *     allocator); the library never allocates, frees or synchronises;
+ *   - activations are NHWC ("pixel rows"): element (n,h,w,c) of a tensor with
+ *     channel stride `ld` lives at ((n*H+h)*W+w)*ld + c, so a channel slice of a
+ *     wider (concatenated) tensor is addressed with the same pointer arithmetic;
+ *   - `dtype` selects the storage/MFMA input type of activations and packed
+ *     weights (MI355_F32: v_mfma_f32_32x32x2_f32, MI355_BF16:
+ *     v_mfma_f32_32x32x16_bf16); accumulation, statistics, parameters and
+ *     parameter gradients are always fp32;
+ *   - every launcher takes the hipStream_t to enqueue on and returns 0 or a
+ *     negative MI355_ERR_* / positive hipError_t; mi355_last_error() gives text.
+ */
+#ifndef MI355CONV_H_
+#define MI355CONV_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* mi355_stream_t; /* == hipStream_t */
+
+enum { MI355_F32 = 0, MI355_BF16 = 1 };
+enum { MI355_OK = 0, MI355_ERR_ARG = -1, MI355_ERR_UNSUPPORTED = -2 };
+
+int mi355_version(void);
+const char* mi355_last_error(void);
+
+/* ---- layout staging ------------------------------------------------------------------ */
+
+/* NCHW fp32 network input -> NHWC `dtype` with channels zero-padded to Cpad (multiple of
+ * 32).  Replaces the implicit layout/precision change of `x.to(device)` + autocast,
+ * utils/helpers.py:318-322. */
+int mi355_pack_input_nchw(const float* x, void* y, int N, int C, int H, int W, int Cpad, int dtype,
+                          mi355_stream_t s);
+/* NHWC `dtype` (channel stride ld) -> NCHW fp32 (model outputs / logits). */
+int mi355_unpack_output_nchw(const void* x, float* y, int N, int C, int H, int W, int ld, int dtype,
+                             mi355_stream_t s);
+/* NCHW fp32 -> NHWC `dtype` without padding (incoming output gradients). */
+int mi355_pack_nchw(const float* x, void* y, int N, int C, int H, int W, int ld, int dtype, mi355_stream_t s);
+
+/* fp32 parameter [Co][Ci][KH][KW] -> packed forward weights Wf[Co][KH*KW][Cip] and (if wb != NULL)
+ * packed data-gradient weights Wb[Cip][KH*KW][Co] (Cip = Ci padded up to a multiple of 32, zero
+ * filled).  `transposed` != 0 reads a ConvTranspose2d parameter [Ci][Co][KH][KW] instead
+ * (models/segmentation_models/ResnetUnet.py:21). */
+int mi355_pack_conv_weight(const float* w, void* wf, void* wb, int Co, int Ci, int Cip, int KH, int KW,
+                           int transposed, int dtype, mi355_stream_t s);
+
+/* ---- implicit-GEMM convolution on MFMA -------------------------------------------------
+ * out[m][j] (+)= bias[j] + sum_{kh,kw,c} in[src(m,kh,kw)][c] * wk[j][kh*KW+kw][c]
+ *   m = (n,ho,wo);  t = o*mul + k*kmul + off (per axis);  valid iff t % div == 0 and
+ *   0 <= t/div < (up ? 2*Hi : Hi);  src row = t/div (>>1 when `up`: fused nearest x2).
+ * forward conv stride s pad p : mul=s, kmul=+1, off=-p, div=1, wk = Wf      (nn.Conv2d forward,
+ *   models/segmentation_models/AttentionUNet.py:6,9,20,32,36,40,84; ResNet.py:17-20,102)
+ * data gradient stride s pad p: mul=1, kmul=-1, off=+p, div=s, wk = Wb     (convolution_backward
+ *   input grad, reached from loss.backward(), utils/helpers.py:329)
+ * ConvTranspose2d(k,s)        : data-gradient form with wk = Wf of the transposed parameter
+ *   (ResnetUnet.py:21,51).
+ * Ci % 32 == 0 (16 for fp32), Co % 32 == 0.  accumulate != 0 adds into `out`. */
+int mi355_conv2d_igemm(const void* in, const void* wk, const float* bias, void* out,
+                       int N, int Hi, int Wi, int Ci, int ldi,
+                       int Ho, int Wo, int Co, int ldo,
+                       int KH, int KW, int mul, int kmul, int off, int div, int up,
+                       int accumulate, int dtype, mi355_stream_t s);
+
+/* Weight gradient: ws[split][Co][KH*KW][Ci] = sum over the split's pixel range of
+ * dy[m][co] * x[src(m,kh,kw)][ci] (forward addressing as above), then
+ * mi355_conv2d_wgrad_reduce sums the splits into the fp32 parameter-gradient layout
+ * [Co][Ci_real][KH][KW] (or [Ci_real][Co][KH][KW] when transposed), beta in {0,1}.
+ * (convolution_backward weight grad, utils/helpers.py:329.) */
+int mi355_conv2d_wgrad_splits(int N, int Ho, int Wo, int Ci, int Co, int KH, int KW);
+int mi355_conv2d_wgrad(const void* x, const void* dy, float* ws, int splits,
+                       int N, int Hi, int Wi, int Ci, int ldx,
+                       int Ho, int Wo, int Co, int ldy,
+                       int KH, int KW, int stride, int pad, int up, int dtype, mi355_stream_t s);
+int mi355_conv2d_wgrad_reduce(const float* ws, int splits, float* dw, int Co, int Ci, int Ci_real,
+                              int KH, int KW, int transposed, float beta, mi355_stream_t s);
+
+/* ---- per-channel reductions / BatchNorm (nn.BatchNorm2d, AttentionUNet.py:7,10,21,34,38,42) -- */
+
+/* partial[(b*2+0)*C + c] = sum over block b's rows of x[m][c]; [(b*2+1)*C+c] = sum of squares.
+ * nblocks = mi355_rowreduce_blocks(M). */
+int mi355_rowreduce_blocks(long long M);
+int mi355_bn_stats(const void* x, float* partial, long long M, int C, int ld, int dtype, mi355_stream_t s);
+/* Train-mode finalize: batch mean / biased var -> scale = gamma*invstd, shift = beta - mean*scale,
+ * saves mean/invstd, updates running stats (momentum, unbiased var) and num_batches_tracked. */
+int mi355_bn_finalize(const float* partial, int nblocks, long long M, int C, const float* gamma,
+                      const float* beta, float* running_mean, float* running_var, int64_t* nbt,
+                      float momentum, float eps, float* scale, float* shift, float* mean, float* invstd,
+                      mi355_stream_t s);
+/* Eval-mode scale/shift from running stats. */
+int mi355_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                         const float* running_var, float eps, int C, float* scale, float* shift,
+                         mi355_stream_t s);
+/* y = act(x*scale[c]+shift[c] (+ x2*scale2[c]+shift2[c] | + r)) ; act: 0 none, 1 relu.
+ * x2/scale2/shift2 optional second normalised operand (attention gate g1+x1,
+ * AttentionUNet.py:51); `res` optional already-activated residual (ResNet.py:43). */
+int mi355_bn_act(const void* x, int ldx, const float* scale, const float* shift,
+                 const void* x2, int ldx2, const float* scale2, const float* shift2,
+                 const void* res, int ldr, void* y, int ldy, long long M, int C, int act, int dtype,
+                 mi355_stream_t s);
+/* Backward reductions for y = act(bn(x) [+ other]) given dL/dy:
+ * partial sums of g and g*xhat per channel, g = dy * (y > 0 if act). */
+int mi355_bn_bwd_reduce(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,
+                        const float* mean, const float* invstd, float* partial, long long M, int C,
+                        int act, int dtype, mi355_stream_t s);
+/* sums[0..C) = sum g (dbeta), sums[C..2C) = sum g*xhat (dgamma); beta-accumulate into dgamma/dbeta. */
+int mi355_bn_bwd_finalize(const float* partial, int nblocks, int C, float* sums, float* dgamma, float* dbeta,
+                          float acc, mi355_stream_t s);
+/* dx = gamma*invstd*(g - sum_g/M - xhat*sum_gx/M); optional dres = g (residual / second operand
+ * gradient, pre-normalisation), optional bias-gradient partials (column sums of dx). */
+int mi355_bn_bwd_apply(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,
+                       const float* gamma, const float* mean, const float* invstd, const float* sums,
+                       void* dx, int lddx, void* dres, int lddres, float* dbias_partial,
+                       long long M, int C, int act, int dtype, mi355_stream_t s);
+/* out[c] (+)= sum_b partial[b*stride*C + c]  (used for conv bias gradients). */
+int mi355_colsum_finalize(const float* partial, int nblocks, int stride, int C, float* out, float acc,
+                          mi355_stream_t s);
+/* partial column sums of a plain tensor (bias gradient of convs without BN). */
+int mi355_colsum(const void* x, int ld, float* partial, long long M, int C, int dtype, mi355_stream_t s);
+
+/* ---- pooling / resampling / elementwise ------------------------------------------------- */
+/* nn.MaxPool2d(k, s, p) forward and backward (AttentionUNet.py:61; ResNet.py:105); backward routes
+ * to the first maximum in window scan order, accumulating into dx when accumulate != 0. */
+int mi355_maxpool_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C,
+                      int k, int stride, int pad, int dtype, mi355_stream_t s);
+int mi355_maxpool_bwd(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx,
+                      int N, int H, int W, int C, int k, int stride, int pad, int accumulate, int dtype,
+                      mi355_stream_t s);
+/* gradient of nn.Upsample(scale_factor=2) (nearest): dx[h][w] = sum of the 2x2 block of dy. */
+int mi355_upsample2_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int H, int W, int C,
+                        int accumulate, int dtype, mi355_stream_t s);
+/* y = a + b (b optional => copy), strided. */
+int mi355_add(const void* a, int lda, const void* b, int ldb, void* y, int ldy, long long M, int C, int dtype,
+              mi355_stream_t s);
+/* y = relu(x) forward; dx = dy * (y > 0) backward (VGG.py:10). */
+int mi355_relu_fwd(const void* x, int ldx, void* y, int ldy, long long M, int C, int dtype, mi355_stream_t s);
+int mi355_relu_bwd(const void* dy, int lddy, const void* y, int ldy, void* dx, int lddx, long long M, int C,
+                   int dtype, mi355_stream_t s);
+
+/* ---- attention gate / single-output 1x1 conv (AttentionUNet.py:29-54, 84) ------------------ */
+/* z[m] = b + sum_c x[m][c]*w[c]  (Conv2d(C,1,1)); optional per-block partial (sum z, sum z^2). */
+int mi355_rowdot_fwd(const void* x, int ldx, const float* w, const float* b, float* z, float* partial,
+                     long long M, int C, int dtype, mi355_stream_t s);
+/* dx[m][c] (+)= dz[m]*w[c] (masked by xmask>0 if given); partial dw[c] = sum_m dz[m]*x[m][c], db. */
+int mi355_rowdot_bwd(const float* dz, const void* x, int ldx, const float* w, void* dx, int lddx,
+                     float* partial, long long M, int C, int relu_mask, int dtype, mi355_stream_t s);
+/* y[m][c] = x[m][c] * sigmoid(z[m]*scale[0]+shift[0]) */
+int mi355_gate_mul_fwd(const void* x, int ldx, const float* z, const float* scale, const float* shift,
+                       void* y, int ldy, long long M, int C, int dtype, mi355_stream_t s);
+/* dx (+)= dy*psi ; dzn[m] = (sum_c dy*x) * psi*(1-psi); partial (sum dzn, sum dzn*zhat). */
+int mi355_gate_mul_bwd(const void* dy, int lddy, const void* x, int ldx, const float* z, const float* scale,
+                       const float* shift, const float* mean, const float* invstd, void* dx, int lddx,
+                       int accumulate, float* dzn, float* partial, long long M, int C, int dtype,
+                       mi355_stream_t s);
+/* scalar-field BN backward: dz = gamma*invstd*(dzn - S0/M - zhat*S1/M). */
+int mi355_bn1_bwd_apply(const float* dzn, const float* z, const float* gamma, const float* mean,
+                        const float* invstd, const float* sums, float* dz, long long M, mi355_stream_t s);
+
+/* ---- heads (ResNet.py:112-115, VGG.py:109-119) --------------------------------------------- */
+int mi355_global_pool_fwd(const void* x, int ldx, float* y, int32_t* argmax, int N, int HW, int C, int is_max,
+                          int dtype, mi355_stream_t s);
+int mi355_global_pool_bwd(const float* dy, const int32_t* argmax, void* dx, int lddx, int N, int HW, int C,
+                          int is_max, int dtype, mi355_stream_t s);
+/* y[b][o] = act(bias[o] + sum_i x[b][i]*w[o][i]) (fp32, tiny M); backward pieces. */
+int mi355_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int I, int O, int relu,
+                     mi355_stream_t s);
+int mi355_linear_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw,
+                     float* db, int B, int I, int O, int relu, float beta, mi355_stream_t s);
+/* inverted dropout with a Philox-style counter hash: mask bit kept for backward. */
+int mi355_dropout_fwd(const float* x, float* y, uint8_t* mask, long long n, float p, uint64_t seed,
+                      mi355_stream_t s);
+int mi355_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, long long n, float p, mi355_stream_t s);
+
+/* ---- losses (utils/helpers.py:244-246) ---------------------------------------------------- */
+/* BCEWithLogitsLoss (mean): loss[0] and dz = (sigmoid(z)-t)/n * gscale[0] (NCHW fp32 with C==1 is
+ * the same memory as NHWC, so logits/targets are taken as flat arrays). */
+int mi355_bce_logits(const float* z, const float* t, float* loss, float* dz, const float* gscale, long long n,
+                     mi355_stream_t s);
+/* CrossEntropyLoss(label_smoothing): loss[0], dz[B][C]. */
+int mi355_ce_smooth(const float* z, const int64_t* y, float* loss, float* dz, const float* gscale, int B,
+                    int C, float smoothing, mi355_stream_t s);
+
+/* ---- optimiser on flat fp32 buffers (utils/helpers.py:251,304,332-336) ---------------------- */
+/* sumsq partials of a flat gradient buffer; nblocks = mi355_rowreduce_blocks(n). */
+int mi355_sumsq_partial(const float* g, float* partial, long long n, mi355_stream_t s);
+/* norm[0] = sqrt(sum partial); coef[0] = min(1, max_norm/(norm+1e-6)) (clip_grad_norm_);
+ * found_inf[0] = 1 if the norm is not finite. */
+int mi355_clip_coef(const float* partial, int nblocks, float max_norm, float inv_scale, float* norm,
+                    float* coef, float* found_inf, mi355_stream_t s);
+/* AdamW, decoupled decay; g is multiplied by coef[0]*inv_scale first; skipped when found_inf[0] != 0.
+ * step_count is read from device memory (graph-capturable). */
+int mi355_adamw(float* p, const float* g, float* m, float* v, long long n, const float* lr, float beta1,
+                float beta2, float eps, float wd, const float* coef, float inv_scale, const float* found_inf,
+                const int32_t* step, mi355_stream_t s);
+int mi355_fill_f32(float* p, float v, long long n, mi355_stream_t s);
+
+/* ---- segmentation metrics counters (utils/tester.py:92-193; helpers.py:223-227) ------------- */
+/* per sample b: counts[b*4+{0,1,2,3}] = tp, pred-positive, target-positive, equal   (p = prob > thr) */
+int mi355_seg_counts(const float* prob_or_logit, const float* target, float* counts, int B, long long per,
+                     int is_logit, float thr, mi355_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355CONV_H_ */

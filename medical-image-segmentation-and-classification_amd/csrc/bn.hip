@@ -1,0 +1,302 @@
+// BatchNorm2d pieces for NHWC tensors (train-mode statistics, apply(+ReLU,+add), backward).
+// All kernels are HBM-bound streaming passes built on rowred.hpp (16-B per lane, deterministic
+// per-workgroup partials, fp32/fp64 statistics regardless of the storage dtype).
+#include "rowred.hpp"
+
+// ---- forward statistics --------------------------------------------------------------------------
+template <typename T> struct BnStatsOp {
+  static constexpr int NQ = 2;
+  typedef double Acc;
+  static constexpr int EPC = 16 / (int)sizeof(T);
+  const T* x;
+  int ld;
+  __device__ void load_cols(int) {}
+  __device__ void apply(size_t row, int c0, Acc (&acc)[NQ][EPC]) const {
+    const Vec16<T> v = ld16<T>(x + row * ld + c0);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const double f = (double)to_f32<T>(v.v[e]);
+      acc[0][e] += f;
+      acc[1][e] += f * f;
+    }
+  }
+};
+
+extern "C" int mi355_rowreduce_blocks(long long M) { return rowreduce_blocks(M); }
+
+extern "C" int mi355_bn_stats(const void* x, float* partial, long long M, int C, int ld, int dtype, mi355_stream_t s) {
+  MI355_CHECK_ARG(x && partial && M > 0, "bn_stats: bad arguments");
+  if (dtype == MI355_BF16) {
+    BnStatsOp<bf16_t> op{(const bf16_t*)x, ld};
+    return rowred_launch<bf16_t>(op, M, C, partial, (hipStream_t)s);
+  }
+  BnStatsOp<float> op{(const float*)x, ld};
+  return rowred_launch<float>(op, M, C, partial, (hipStream_t)s);
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nblocks, double M, int C,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ rmean, float* __restrict__ rvar, int64_t* nbt, float momentum,
+                                   float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) *nbt += 1;
+  if (c >= C) return;
+  double s = 0, q = 0;
+  for (int b = 0; b < nblocks; ++b) {
+    s += (double)partial[((size_t)b * 2 + 0) * C + c];
+    q += (double)partial[((size_t)b * 2 + 1) * C + c];
+  }
+  const double mean = s / M;
+  double var = q / M - mean * mean;
+  if (var < 0) var = 0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (rmean) {
+    const double unb = M > 1 ? var * M / (M - 1) : var;
+    rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * mean);
+    rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unb);
+  }
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  mean_out[c] = (float)mean;
+  invstd_out[c] = invstd;
+}
+
+extern "C" int mi355_bn_finalize(const float* partial, int nblocks, long long M, int C, const float* gamma,
+                                 const float* beta, float* running_mean, float* running_var, int64_t* nbt,
+                                 float momentum, float eps, float* scale, float* shift, float* mean, float* invstd,
+                                 mi355_stream_t s) {
+  MI355_CHECK_ARG(partial && gamma && beta && scale && shift && mean && invstd, "bn_finalize: null pointer");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, (hipStream_t)s, partial, nblocks, (double)M, C,
+                     gamma, beta, running_mean, running_var, nbt, momentum, eps, scale, shift, mean, invstd);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                      int C, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = gamma[c] / sqrtf(rv[c] + eps);
+  scale[c] = sc;
+  shift[c] = beta[c] - rm[c] * sc;
+}
+
+extern "C" int mi355_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                                    const float* running_var, float eps, int C, float* scale, float* shift,
+                                    mi355_stream_t s) {
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, (hipStream_t)s, gamma, beta, running_mean,
+                     running_var, eps, C, scale, shift);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+// ---- apply (+ second normalised operand, + residual, + ReLU) ------------------------------------------
+template <typename T> struct BnActOp {
+  static constexpr int EPC = 16 / (int)sizeof(T);
+  const T* x; int ldx; const float* scale; const float* shift;
+  const T* x2; int ldx2; const float* scale2; const float* shift2;
+  const T* res; int ldr;
+  T* y; int ldy;
+  int act;
+  __device__ void apply(size_t row, int c0) const {
+    const Vec16<T> v = ld16<T>(x + row * ldx + c0);
+    float f[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      f[e] = to_f32<T>(v.v[e]);
+      if (scale) f[e] = f[e] * scale[c0 + e] + shift[c0 + e];
+    }
+    if (x2) {
+      const Vec16<T> v2 = ld16<T>(x2 + row * ldx2 + c0);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) f[e] += to_f32<T>(v2.v[e]) * scale2[c0 + e] + shift2[c0 + e];
+    }
+    if (res) {
+      const Vec16<T> vr = ld16<T>(res + row * ldr + c0);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) f[e] += to_f32<T>(vr.v[e]);
+    }
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) o.v[e] = from_f32<T>(act ? fmaxf(f[e], 0.f) : f[e]);
+    st16<T>(y + row * ldy + c0, o);
+  }
+};
+
+extern "C" int mi355_bn_act(const void* x, int ldx, const float* scale, const float* shift, const void* x2, int ldx2,
+                            const float* scale2, const float* shift2, const void* res, int ldr, void* y, int ldy,
+                            long long M, int C, int act, int dtype, mi355_stream_t s) {
+  MI355_CHECK_ARG(x && y && M > 0, "bn_act: bad arguments");
+  MI355_CHECK_ARG(!x2 || (scale2 && shift2), "bn_act: second operand needs scale2/shift2");
+  if (dtype == MI355_BF16) {
+    BnActOp<bf16_t> op{(const bf16_t*)x, ldx, scale, shift, (const bf16_t*)x2, ldx2, scale2, shift2,
+                       (const bf16_t*)res, ldr, (bf16_t*)y, ldy, act};
+    return rowmap_launch<bf16_t>(op, M, C, (hipStream_t)s);
+  }
+  BnActOp<float> op{(const float*)x, ldx, scale, shift, (const float*)x2, ldx2, scale2, shift2,
+                    (const float*)res, ldr, (float*)y, ldy, act};
+  return rowmap_launch<float>(op, M, C, (hipStream_t)s);
+}
+
+// ---- backward ------------------------------------------------------------------------------------
+template <typename T> struct BnBwdReduceOp {
+  static constexpr int NQ = 2;
+  typedef float Acc;
+  static constexpr int EPC = 16 / (int)sizeof(T);
+  const T* dy; int lddy; const T* y; int ldy; const T* x; int ldx;
+  const float* mean; const float* invstd; int act;
+  float mu[EPC], is[EPC];
+  __device__ void load_cols(int c0) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { mu[e] = mean[c0 + e]; is[e] = invstd[c0 + e]; }
+  }
+  __device__ void apply(size_t row, int c0, Acc (&acc)[NQ][EPC]) const {
+    const Vec16<T> g = ld16<T>(dy + row * lddy + c0);
+    const Vec16<T> xv = ld16<T>(x + row * ldx + c0);
+    Vec16<T> yv;
+    if (act) yv = ld16<T>(y + row * ldy + c0);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      float gg = to_f32<T>(g.v[e]);
+      if (act && !(to_f32<T>(yv.v[e]) > 0.f)) gg = 0.f;
+      acc[0][e] += gg;
+      acc[1][e] += gg * (to_f32<T>(xv.v[e]) - mu[e]) * is[e];
+    }
+  }
+};
+
+extern "C" int mi355_bn_bwd_reduce(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,
+                                   const float* mean, const float* invstd, float* partial, long long M, int C, int act,
+                                   int dtype, mi355_stream_t s) {
+  MI355_CHECK_ARG(dy && x && mean && invstd && partial && (!act || y), "bn_bwd_reduce: null pointer");
+  if (dtype == MI355_BF16) {
+    BnBwdReduceOp<bf16_t> op{(const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, (const bf16_t*)x, ldx, mean, invstd, act};
+    return rowred_launch<bf16_t>(op, M, C, partial, (hipStream_t)s);
+  }
+  BnBwdReduceOp<float> op{(const float*)dy, lddy, (const float*)y, ldy, (const float*)x, ldx, mean, invstd, act};
+  return rowred_launch<float>(op, M, C, partial, (hipStream_t)s);
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, float* __restrict__ sums,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float accf) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0, s1 = 0;
+  for (int b = 0; b < nblocks; ++b) {
+    s0 += (double)partial[((size_t)b * 2 + 0) * C + c];
+    s1 += (double)partial[((size_t)b * 2 + 1) * C + c];
+  }
+  sums[c] = (float)s0;
+  sums[C + c] = (float)s1;
+  if (dbeta) dbeta[c] = (accf != 0.f ? accf * dbeta[c] : 0.f) + (float)s0;
+  if (dgamma) dgamma[c] = (accf != 0.f ? accf * dgamma[c] : 0.f) + (float)s1;
+}
+
+extern "C" int mi355_bn_bwd_finalize(const float* partial, int nblocks, int C, float* sums, float* dgamma, float* dbeta,
+                                     float acc, mi355_stream_t s) {
+  MI355_CHECK_ARG(partial && sums, "bn_bwd_finalize: null pointer");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, (hipStream_t)s, partial, nblocks, C, sums,
+                     dgamma, dbeta, acc);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+template <typename T> struct BnBwdApplyOp {
+  static constexpr int NQ = 1;
+  typedef float Acc;
+  static constexpr int EPC = 16 / (int)sizeof(T);
+  const T* dy; int lddy; const T* y; int ldy; const T* x; int ldx;
+  const float* gamma; const float* mean; const float* invstd; const float* sums;
+  T* dx; int lddx; T* dres; int lddres;
+  float invM; int C; int act;
+  float mu[EPC], is[EPC], k0[EPC], k1[EPC], gi[EPC];
+  __device__ void load_cols(int c0) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      mu[e] = mean[c0 + e];
+      is[e] = invstd[c0 + e];
+      gi[e] = gamma[c0 + e] * is[e];
+      k0[e] = sums[c0 + e] * invM;
+      k1[e] = sums[C + c0 + e] * invM;
+    }
+  }
+  __device__ void apply(size_t row, int c0, Acc (&acc)[NQ][EPC]) const {
+    const Vec16<T> g = ld16<T>(dy + row * lddy + c0);
+    const Vec16<T> xv = ld16<T>(x + row * ldx + c0);
+    Vec16<T> yv;
+    if (act) yv = ld16<T>(y + row * ldy + c0);
+    Vec16<T> o, r;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      float gg = to_f32<T>(g.v[e]);
+      if (act && !(to_f32<T>(yv.v[e]) > 0.f)) gg = 0.f;
+      const float xh = (to_f32<T>(xv.v[e]) - mu[e]) * is[e];
+      const float d = gi[e] * (gg - k0[e] - xh * k1[e]);
+      o.v[e] = from_f32<T>(d);
+      r.v[e] = from_f32<T>(gg);
+      acc[0][e] += d;
+    }
+    st16<T>(dx + row * lddx + c0, o);
+    if (dres) st16<T>(dres + row * lddres + c0, r);
+  }
+};
+
+extern "C" int mi355_bn_bwd_apply(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,
+                                  const float* gamma, const float* mean, const float* invstd, const float* sums, void* dx,
+                                  int lddx, void* dres, int lddres, float* dbias_partial, long long M, int C, int act,
+                                  int dtype, mi355_stream_t s) {
+  MI355_CHECK_ARG(dy && x && gamma && mean && invstd && sums && dx && (!act || y), "bn_bwd_apply: null pointer");
+  const float invM = (float)(1.0 / (double)M);
+  if (dtype == MI355_BF16) {
+    BnBwdApplyOp<bf16_t> op{(const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, (const bf16_t*)x, ldx, gamma, mean, invstd,
+                            sums, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, invM, C, act};
+    return rowred_launch<bf16_t>(op, M, C, dbias_partial, (hipStream_t)s);
+  }
+  BnBwdApplyOp<float> op{(const float*)dy, lddy, (const float*)y, ldy, (const float*)x, ldx, gamma, mean, invstd, sums,
+                         (float*)dx, lddx, (float*)dres, lddres, invM, C, act};
+  return rowred_launch<float>(op, M, C, dbias_partial, (hipStream_t)s);
+}
+
+// ---- plain column sums (bias gradients) -------------------------------------------------------------
+template <typename T> struct ColSumOp {
+  static constexpr int NQ = 1;
+  typedef float Acc;
+  static constexpr int EPC = 16 / (int)sizeof(T);
+  const T* x; int ld;
+  __device__ void load_cols(int) {}
+  __device__ void apply(size_t row, int c0, Acc (&acc)[NQ][EPC]) const {
+    const Vec16<T> v = ld16<T>(x + row * ld + c0);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[0][e] += to_f32<T>(v.v[e]);
+  }
+};
+
+extern "C" int mi355_colsum(const void* x, int ld, float* partial, long long M, int C, int dtype, mi355_stream_t s) {
+  MI355_CHECK_ARG(x && partial, "colsum: null pointer");
+  if (dtype == MI355_BF16) {
+    ColSumOp<bf16_t> op{(const bf16_t*)x, ld};
+    return rowred_launch<bf16_t>(op, M, C, partial, (hipStream_t)s);
+  }
+  ColSumOp<float> op{(const float*)x, ld};
+  return rowred_launch<float>(op, M, C, partial, (hipStream_t)s);
+}
+
+__global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nblocks, int stride, int C,
+                                       float* __restrict__ out, float accf) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0;
+  for (int b = 0; b < nblocks; ++b) s0 += (double)partial[(size_t)b * stride * C + c];
+  out[c] = (accf != 0.f ? accf * out[c] : 0.f) + (float)s0;
+}
+
+extern "C" int mi355_colsum_finalize(const float* partial, int nblocks, int stride, int C, float* out, float acc,
+                                     mi355_stream_t s) {
+  MI355_CHECK_ARG(partial && out, "colsum_finalize: null pointer");
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, (hipStream_t)s, partial, nblocks, stride, C,
+                     out, acc);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}

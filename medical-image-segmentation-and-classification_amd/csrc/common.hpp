@@ -1,0 +1,76 @@
+// Shared device/host helpers for libmi355conv (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/mi355conv.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define MI355_WAVE 64
+
+// ---- error plumbing (no exceptions cross the C ABI) -------------------------------------
+void mi355_set_error(const char* fmt, ...);
+#define MI355_FAIL(code, ...)          \
+  do {                                 \
+    mi355_set_error(__VA_ARGS__);      \
+    return (code);                     \
+  } while (0)
+#define MI355_CHECK_ARG(cond, ...)                         \
+  do {                                                     \
+    if (!(cond)) MI355_FAIL(MI355_ERR_ARG, __VA_ARGS__);   \
+  } while (0)
+#define MI355_LAUNCH_CHECK()                                                        \
+  do {                                                                              \
+    hipError_t e__ = hipGetLastError();                                             \
+    if (e__ != hipSuccess) MI355_FAIL((int)e__, "launch failed: %s", hipGetErrorString(e__)); \
+  } while (0)
+
+// ---- scalar conversions ------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// 16-byte vector of T (4 x f32 or 8 x bf16)
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+  static constexpr int N = 4;
+  float v[4];
+};
+template <> struct Vec16<bf16_t> {
+  static constexpr int N = 8;
+  bf16_t v[8];
+};
+
+template <typename T> __device__ __forceinline__ Vec16<T> ld16(const T* p) {
+  Vec16<T> r;
+  *reinterpret_cast<uint4*>(&r) = *reinterpret_cast<const uint4*>(p);
+  return r;
+}
+template <typename T> __device__ __forceinline__ void st16(T* p, const Vec16<T>& r) {
+  *reinterpret_cast<uint4*>(p) = *reinterpret_cast<const uint4*>(&r);
+}
+
+// ---- reductions --------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,305 @@
+// Implicit-GEMM convolution on MFMA for gfx950 (forward conv, data gradient, ConvTranspose).
+//
+//   out[m][j] = bias[j] + sum_{tap,c} in[src(m,tap)][c] * wk[j][tap][c]
+//
+// GEMM view: M = N*Ho*Wo pixel rows, N = Co, K = KH*KW*Ci walked tap-major in BK-channel
+// slabs.  One 256-thread workgroup (4 waves, one per SIMD) owns a 128 x BN output tile.
+// A rows are gathered straight from the NHWC activation (coalesced 16-B pieces of one
+// pixel's channel run, zero for padding / stride holes), B rows from the packed weights
+// [Co][tap][Ci]; both are register-staged (issue early, write late) into a double-buffered,
+// XOR-swizzled LDS image so every ds_read_b128 fragment read is bank-conflict free.
+//   bf16: v_mfma_f32_32x32x16_bf16, BK = 64 (or 32) channels per slab
+//   fp32: v_mfma_f32_32x32x2_f32 (exact fmaf chain), BK = 16
+#include "common.hpp"
+
+struct ConvArgs {
+  const void* in;
+  const void* wk;
+  const float* bias;
+  void* out;
+  int N, Hi, Wi, Ci, ldi;
+  int Ho, Wo, Co, ldo;
+  int KH, KW;
+  int mul, kmul, off, dshift, up;
+  int accumulate;
+  int M;        // N*Ho*Wo
+  int HoWo;
+  int Hlog, Wlog;   // logical (post-upsample) input extent
+};
+
+template <typename T> struct Frag;   // 16-byte LDS fragment and its MFMA step
+template <> struct Frag<bf16_t> {
+  static __device__ __forceinline__ void mma(const uint4& a, const uint4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
+                                                0, 0);
+  }
+};
+template <> struct Frag<float> {
+  static __device__ __forceinline__ void mma(const uint4& a, const uint4& b, f32x16& c) {
+    const f32x4 av = __builtin_bit_cast(f32x4, a), bv = __builtin_bit_cast(f32x4, b);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bv[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bv[3], c, 0, 0, 0);
+  }
+};
+
+template <typename T, int BN, int BK>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+  constexpr int BM = 128;
+  constexpr int EPC = 16 / (int)sizeof(T);    // elements per 16-B chunk
+  constexpr int CPR = BK / EPC;               // chunks per LDS row
+  constexpr int P = BK * (int)sizeof(T);      // LDS row pitch in bytes (64 or 128)
+  constexpr int RPBS = (P == 128) ? 1 : 2;    // log2(rows per 256-B bank row)
+  constexpr int RPP = 256 / CPR;              // rows staged per pass of the 256 threads
+  constexpr int A_IT = BM / RPP;
+  constexpr int B_IT = (BN >= RPP) ? BN / RPP : 1;
+  constexpr int WM = (BN == 32) ? 4 : 2, WN = 4 / WM;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int MI = WTM / 32, NI = WTN / 32;
+  constexpr int KQ = CPR / 2;
+  constexpr int A_BYTES = BM * P, B_BYTES = BN * P, STAGE = A_BYTES + B_BYTES;
+  constexpr bool LDS_EPI = sizeof(T) == 2;
+  constexpr int C_PITCH = BN * (int)sizeof(T) + 16;
+  constexpr int C_BYTES = LDS_EPI ? BM * C_PITCH : 0;
+  constexpr int LDS_BYTES = (2 * STAGE > C_BYTES) ? 2 * STAGE : C_BYTES;
+  static_assert(P == 64 || P == 128, "row pitch");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r32 = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int NT = a.Co / BN;
+  const int mt = blockIdx.x / NT, nt = blockIdx.x - mt * NT;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const T* __restrict__ in = reinterpret_cast<const T*>(a.in);
+  const T* __restrict__ wk = reinterpret_cast<const T*>(a.wk);
+
+  // ---- per-thread staging assignment -------------------------------------------------------
+  const int chunk = tid % CPR, srow = tid / CPR;
+  int a_nb[A_IT], a_hs[A_IT], a_ws[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int m = m0 + srow + i * RPP;
+    if (m < a.M) {
+      const int n = m / a.HoWo;
+      const int rem = m - n * a.HoWo;
+      const int ho = rem / a.Wo;
+      const int wo = rem - ho * a.Wo;
+      a_nb[i] = n * a.Hi;
+      a_hs[i] = ho * a.mul + a.off;
+      a_ws[i] = wo * a.mul + a.off;
+    } else {
+      a_nb[i] = 0;
+      a_hs[i] = -(1 << 28);   // never passes the range check
+      a_ws[i] = 0;
+    }
+  }
+  const int taps = a.KH * a.KW;
+  const size_t wrow = (size_t)taps * a.Ci;
+  const int dmask = (1 << a.dshift) - 1;
+
+  uint4 ra[A_IT], rb[B_IT];
+  auto load_tile = [&](int kh, int kw, int c0) {
+    const int dh = kh * a.kmul, dw = kw * a.kmul;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      int th = a_hs[i] + dh, tw = a_ws[i] + dw;
+      bool ok = ((th | tw) & dmask) == 0;
+      th >>= a.dshift;
+      tw >>= a.dshift;
+      ok = ok && (unsigned)th < (unsigned)a.Hlog && (unsigned)tw < (unsigned)a.Wlog;
+      th >>= a.up;
+      tw >>= a.up;
+      if (ok) {
+        const T* p = in + ((size_t)(a_nb[i] + th) * a.Wi + tw) * a.ldi + c0 + chunk * EPC;
+        ra[i] = *reinterpret_cast<const uint4*>(p);
+      } else {
+        ra[i] = make_uint4(0, 0, 0, 0);
+      }
+    }
+    const int tap = kh * a.KW + kw;
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int row = srow + i * RPP;
+      if (BN >= RPP || row < BN) {
+        const T* p = wk + (size_t)(n0 + row) * wrow + (size_t)tap * a.Ci + c0 + chunk * EPC;
+        rb[i] = *reinterpret_cast<const uint4*>(p);
+      }
+    }
+  };
+  auto swz = [](int row, int c) { return (c ^ ((row >> RPBS) & (CPR - 1))) << 4; };
+  auto store_tile = [&](int stage) {
+    unsigned char* la = lds + stage * STAGE;
+    unsigned char* lb = la + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int row = srow + i * RPP;
+      *reinterpret_cast<uint4*>(la + row * P + swz(row, chunk)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int row = srow + i * RPP;
+      if (BN >= RPP || row < BN) *reinterpret_cast<uint4*>(lb + row * P + swz(row, chunk)) = rb[i];
+    }
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int KT = taps * (a.Ci / BK);
+  int kh = 0, kw = 0, c0 = 0;
+  load_tile(0, 0, 0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    const bool more = (kt + 1) < KT;
+    if (more) {
+      c0 += BK;
+      if (c0 == a.Ci) {
+        c0 = 0;
+        if (++kw == a.KW) {
+          kw = 0;
+          ++kh;
+        }
+      }
+      load_tile(kh, kw, c0);
+    }
+    const unsigned char* la = lds + cur * STAGE;
+    const unsigned char* lb = la + A_BYTES;
+#pragma unroll
+    for (int kq = 0; kq < KQ; ++kq) {
+      const int c = kq * 2 + h;
+      uint4 af[MI], bf[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int row = wm * WTM + mi * 32 + r32;
+        af[mi] = *reinterpret_cast<const uint4*>(la + row * P + swz(row, c));
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int row = wn * WTN + ni * 32 + r32;
+        bf[ni] = *reinterpret_cast<const uint4*>(lb + row * P + swz(row, c));
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) Frag<T>::mma(af[mi], bf[ni], acc[mi][ni]);
+    }
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------------
+  T* __restrict__ out = reinterpret_cast<T*>(a.out);
+  float bcol[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+    bcol[ni] = a.bias ? a.bias[n0 + wn * WTN + ni * 32 + r32] : 0.f;
+
+  if constexpr (!LDS_EPI) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int m = m0 + row;
+          if (m < a.M) {
+            T* p = out + (size_t)m * a.ldo + n0 + wn * WTN + ni * 32 + r32;
+            float v = acc[mi][ni][r] + bcol[ni];
+            if (a.accumulate) v += to_f32<T>(*p);
+            *p = from_f32<T>(v);
+          }
+        }
+  } else {
+    // stage the tile through LDS so that global stores are 16-B, row-contiguous
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int col = wn * WTN + ni * 32 + r32;
+          *reinterpret_cast<T*>(lds + row * C_PITCH + col * (int)sizeof(T)) = from_f32<T>(acc[mi][ni][r] + bcol[ni]);
+        }
+    __syncthreads();
+    constexpr int CPRC = BN / EPC;
+    for (int id = tid; id < BM * CPRC; id += 256) {
+      const int row = id / CPRC, c = id - row * CPRC;
+      const int m = m0 + row;
+      if (m < a.M) {
+        T* p = out + (size_t)m * a.ldo + n0 + c * EPC;
+        Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(lds + row * C_PITCH + c * 16);
+        if (a.accumulate) {
+          const Vec16<T> o = ld16<T>(p);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) v.v[e] = from_f32<T>(to_f32<T>(v.v[e]) + to_f32<T>(o.v[e]));
+        }
+        st16<T>(p, v);
+      }
+    }
+  }
+}
+
+template <typename T, int BN, int BK>
+static int launch(const ConvArgs& a, hipStream_t s) {
+  const int grid = ceil_div(a.M, 128) * (a.Co / BN);
+  hipLaunchKernelGGL((conv_igemm_kernel<T, BN, BK>), dim3(grid), dim3(256), 0, s, a);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+template <typename T, int BK>
+static int launch_bn(const ConvArgs& a, hipStream_t s) {
+  if (a.Co % 128 == 0) return launch<T, 128, BK>(a, s);
+  if (a.Co % 64 == 0) return launch<T, 64, BK>(a, s);
+  return launch<T, 32, BK>(a, s);
+}
+
+extern "C" int mi355_conv2d_igemm(const void* in, const void* wk, const float* bias, void* out, int N, int Hi, int Wi,
+                                  int Ci, int ldi, int Ho, int Wo, int Co, int ldo, int KH, int KW, int mul, int kmul,
+                                  int off, int div, int up, int accumulate, int dtype, mi355_stream_t s) {
+  MI355_CHECK_ARG(in && wk && out, "conv2d_igemm: null pointer");
+  MI355_CHECK_ARG(N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && KH > 0 && KW > 0, "conv2d_igemm: bad extent");
+  MI355_CHECK_ARG(div == 1 || div == 2 || div == 4, "conv2d_igemm: div must be 1, 2 or 4 (got %d)", div);
+  MI355_CHECK_ARG(Co % 32 == 0, "conv2d_igemm: Co=%d must be a multiple of 32", Co);
+  MI355_CHECK_ARG(ldi >= Ci && ldo >= Co, "conv2d_igemm: channel stride smaller than channel count");
+  MI355_CHECK_ARG((long long)N * Ho * Wo < (1ll << 31) && (long long)N * Hi * Wi < (1ll << 31),
+                  "conv2d_igemm: pixel count overflows int32");
+  const int esz = dtype == MI355_BF16 ? 2 : 4;
+  MI355_CHECK_ARG(((uintptr_t)in % 16) == 0 && ((uintptr_t)wk % 16) == 0 && ((uintptr_t)out % 16) == 0 &&
+                      (ldi * esz) % 16 == 0 && (ldo * esz) % 16 == 0,
+                  "conv2d_igemm: pointers / channel strides must be 16-byte aligned");
+  ConvArgs a;
+  a.in = in; a.wk = wk; a.bias = bias; a.out = out;
+  a.N = N; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.ldi = ldi;
+  a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.ldo = ldo;
+  a.KH = KH; a.KW = KW; a.mul = mul; a.kmul = kmul; a.off = off;
+  a.dshift = div == 1 ? 0 : (div == 2 ? 1 : 2);
+  a.up = up ? 1 : 0;
+  a.accumulate = accumulate;
+  a.M = N * Ho * Wo;
+  a.HoWo = Ho * Wo;
+  a.Hlog = up ? 2 * Hi : Hi;
+  a.Wlog = up ? 2 * Wi : Wi;
+  hipStream_t st = (hipStream_t)s;
+  if (dtype == MI355_BF16) {
+    MI355_CHECK_ARG(Ci % 32 == 0, "conv2d_igemm: bf16 needs Ci %% 32 == 0 (got %d)", Ci);
+    if (Ci % 64 == 0) return launch_bn<bf16_t, 64>(a, st);
+    return launch_bn<bf16_t, 32>(a, st);
+  } else if (dtype == MI355_F32) {
+    MI355_CHECK_ARG(Ci % 16 == 0, "conv2d_igemm: fp32 needs Ci %% 16 == 0 (got %d)", Ci);
+    return launch_bn<float, 16>(a, st);
+  }
+  MI355_FAIL(MI355_ERR_UNSUPPORTED, "conv2d_igemm: unknown dtype %d", dtype);
+}

@@ -1,0 +1,293 @@
+// Weight gradient of a convolution as a split-K MFMA GEMM (gfx950).
+//
+//   dW[co][tap][ci] = sum_m dy[m][co] * x[src(m,tap)][ci]          m = (n,ho,wo)
+//
+// GEMM view per tap: rows = co, cols = ci, reduction = output pixels.  Both operands are
+// pixel-major in HBM (NHWC), i.e. the reduction index is the slow one, so each tile is staged
+// [pixel][channel] in LDS exactly as it is read (coalesced 16-B pieces) and the MFMA operand
+// fragments are fetched with the hardware transpose read ds_read_b64_tr_b16 (bf16) or plain
+// conflict-free ds_read_b32 (fp32, one k per lane half).  The pixel range is split over
+// gridDim.z; every split writes its own fp32 slab (deterministic), summed by
+// mi355_conv2d_wgrad_reduce into the parameter-gradient layout.
+#include "common.hpp"
+
+struct WgradArgs {
+  const void* x;
+  const void* dy;
+  float* ws;
+  int N, Hi, Wi, Ci, ldx;
+  int Ho, Wo, Co, ldy;
+  int KH, KW, stride, pad, up;
+  int M, Hlog, Wlog;
+  int chunk;   // pixels per split (multiple of 32)
+};
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+template <typename T, int BCO, int BCI>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+  constexpr int BP = 32;                         // pixels per K step
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr bool BF = sizeof(T) == 2;
+  // LDS pitches: bf16 rows are padded so that the 4 pixel rows of a transpose-read block fall
+  // into disjoint 16-bank windows (64 ch -> 192 B, 128 ch -> 320 B); fp32 rows are natural.
+  constexpr int PO = BF ? (BCO == 128 ? 320 : 192) : BCO * 4;
+  constexpr int PX = BF ? (BCI == 128 ? 320 : 192) : BCI * 4;
+  constexpr int O_BYTES = BP * PO, X_BYTES = BP * PX, STAGE = O_BYTES + X_BYTES;
+  constexpr int CPRO = BCO / EPC, CPRX = BCI / EPC;
+  constexpr int O_IT = BP * CPRO / 256, X_IT = BP * CPRX / 256;
+  constexpr int WTO = BCO / 2, WTI = BCI / 2;     // 2 x 2 waves
+  constexpr int MI = WTO / 32, NI = WTI / 32;
+  static_assert(O_IT >= 1 && X_IT >= 1, "tile too small for 256 threads");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r32 = lane & 31, h = lane >> 5;
+  const int wo_ = wave >> 1, wi_ = wave & 1;
+  const int ciTiles = (a.Ci + BCI - 1) / BCI;
+  const int co0 = (blockIdx.x / ciTiles) * BCO, ci0 = (blockIdx.x % ciTiles) * BCI;
+  const int tap = blockIdx.y, kh = tap / a.KW, kw = tap - kh * a.KW;
+  const int split = blockIdx.z;
+  const int p_begin = split * a.chunk;
+  const int p_end = min(a.M, p_begin + a.chunk);
+  const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
+  const T* __restrict__ dy = reinterpret_cast<const T*>(a.dy);
+
+  // per-thread staging rows
+  int o_row[O_IT], o_c[O_IT];
+#pragma unroll
+  for (int i = 0; i < O_IT; ++i) {
+    const int id = tid + i * 256;
+    o_row[i] = id / CPRO;
+    o_c[i] = id - o_row[i] * CPRO;
+  }
+  int x_row[X_IT], x_c[X_IT], x_n[X_IT], x_ho[X_IT], x_wo[X_IT];
+  const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+  for (int i = 0; i < X_IT; ++i) {
+    const int id = tid + i * 256;
+    x_row[i] = id / CPRX;
+    x_c[i] = id - x_row[i] * CPRX;
+    const int m = p_begin + x_row[i];
+    x_n[i] = m / HoWo;
+    const int rem = m - x_n[i] * HoWo;
+    x_ho[i] = rem / a.Wo;
+    x_wo[i] = rem - x_ho[i] * a.Wo;
+  }
+
+  uint4 ro[O_IT], rx[X_IT];
+  auto load_tile = [&](int p0) {
+#pragma unroll
+    for (int i = 0; i < O_IT; ++i) {
+      const int m = p0 + o_row[i];
+      const int c = co0 + o_c[i] * EPC;
+      if (m < p_end && c < a.Co)
+        ro[i] = *reinterpret_cast<const uint4*>(dy + (size_t)m * a.ldy + c);
+      else
+        ro[i] = make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i) {
+      const int m = p0 + x_row[i];
+      const int c = ci0 + x_c[i] * EPC;
+      int th = x_ho[i] * a.stride + kh - a.pad, tw = x_wo[i] * a.stride + kw - a.pad;
+      bool ok = m < p_end && c < a.Ci && (unsigned)th < (unsigned)a.Hlog && (unsigned)tw < (unsigned)a.Wlog;
+      th >>= a.up;
+      tw >>= a.up;
+      if (ok)
+        rx[i] = *reinterpret_cast<const uint4*>(x + ((size_t)(x_n[i] * a.Hi + th) * a.Wi + tw) * a.ldx + c);
+      else
+        rx[i] = make_uint4(0, 0, 0, 0);
+      // advance this row's pixel coordinate by BP for the next step
+      x_wo[i] += BP;
+      while (x_wo[i] >= a.Wo) {
+        x_wo[i] -= a.Wo;
+        if (++x_ho[i] == a.Ho) {
+          x_ho[i] = 0;
+          ++x_n[i];
+        }
+      }
+    }
+  };
+  auto store_tile = [&](int stage) {
+    unsigned char* lo = lds + stage * STAGE;
+    unsigned char* lx = lo + O_BYTES;
+#pragma unroll
+    for (int i = 0; i < O_IT; ++i) *reinterpret_cast<uint4*>(lo + o_row[i] * PO + o_c[i] * 16) = ro[i];
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i) *reinterpret_cast<uint4*>(lx + x_row[i] * PX + x_c[i] * 16) = rx[i];
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int steps = (p_end - p_begin + BP - 1) / BP;
+  if (steps > 0) {
+    load_tile(p_begin);
+    store_tile(0);
+  }
+  __syncthreads();
+  // transpose-read lane geometry: 16-lane group g = lane>>4 covers channels 16*(g&1).. of the
+  // wave's 32-channel block and pixels 8*(g>>1)..; lane 4q+p of the group addresses pixel row q,
+  // channels 4p..4p+3.
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+  for (int st = 0; st < steps; ++st) {
+    const int cur = st & 1;
+    const bool more = (st + 1) < steps;
+    if (more) load_tile(p_begin + (st + 1) * BP);
+    const unsigned char* lo = lds + cur * STAGE;
+    const unsigned char* lx = lo + O_BYTES;
+    if constexpr (BF) {
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        bf16x8 af[MI], bfr[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const int col = wo_ * WTO + mi * 32 + 16 * tg + 4 * tp;
+          const int prow = ss * 16 + 8 * h + tq;
+          const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lo + prow * PO + col * 2));
+          const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lo + (prow + 4) * PO + col * 2));
+          af[mi] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int col = wi_ * WTI + ni * 32 + 16 * tg + 4 * tp;
+          const int prow = ss * 16 + 8 * h + tq;
+          const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lx + prow * PX + col * 2));
+          const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lx + (prow + 4) * PX + col * 2));
+          bfr[ni] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+      }
+    } else {
+#pragma unroll 4
+      for (int s2 = 0; s2 < BP / 2; ++s2) {
+        const int prow = 2 * s2 + h;
+        float af[MI], bfr[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          af[mi] = *reinterpret_cast<const float*>(lo + prow * PO + (wo_ * WTO + mi * 32 + r32) * 4);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          bfr[ni] = *reinterpret_cast<const float*>(lx + prow * PX + (wi_ * WTI + ni * 32 + r32) * 4);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+      }
+    }
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  const int taps = a.KH * a.KW;
+  float* __restrict__ ws = a.ws + (size_t)split * a.Co * taps * a.Ci;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wo_ * WTO + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int ci = ci0 + wi_ * WTI + ni * 32 + r32;
+        if (co < a.Co && ci < a.Ci) ws[((size_t)co * taps + tap) * a.Ci + ci] = acc[mi][ni][r];
+      }
+}
+
+static void wgrad_tiles(int Co, int Ci, int& bco, int& bci) {
+  bco = (Co % 128 == 0) ? 128 : 64;
+  bci = (Ci % 128 == 0) ? 128 : 64;
+}
+
+extern "C" int mi355_conv2d_wgrad_splits(int N, int Ho, int Wo, int Ci, int Co, int KH, int KW) {
+  int bco, bci;
+  wgrad_tiles(Co, Ci, bco, bci);
+  const long long M = (long long)N * Ho * Wo;
+  const long long tiles = (long long)ceil_div(Co, bco) * ceil_div(Ci, bci) * KH * KW;
+  long long s = 1536 / tiles;                          // ~6 workgroups per CU in flight
+  const long long max_by_pixels = M / 256 > 0 ? M / 256 : 1;
+  if (s > max_by_pixels) s = max_by_pixels;
+  const long long slab = (long long)Co * KH * KW * Ci * 4;
+  while (s > 1 && s * slab > (512ll << 20)) --s;       // bound the fp32 partial workspace
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+template <typename T>
+static int wgrad_launch(const WgradArgs& a, int splits, hipStream_t s) {
+  int bco, bci;
+  wgrad_tiles(a.Co, a.Ci, bco, bci);
+  dim3 grid(ceil_div(a.Co, bco) * ceil_div(a.Ci, bci), a.KH * a.KW, splits);
+  if (bco == 128 && bci == 128)
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, 128, 128>), grid, dim3(256), 0, s, a);
+  else if (bco == 128)
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, 128, 64>), grid, dim3(256), 0, s, a);
+  else if (bci == 128)
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 128>), grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64>), grid, dim3(256), 0, s, a);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+extern "C" int mi355_conv2d_wgrad(const void* x, const void* dy, float* ws, int splits, int N, int Hi, int Wi, int Ci,
+                                  int ldx, int Ho, int Wo, int Co, int ldy, int KH, int KW, int stride, int pad, int up,
+                                  int dtype, mi355_stream_t s) {
+  MI355_CHECK_ARG(x && dy && ws, "conv2d_wgrad: null pointer");
+  MI355_CHECK_ARG(splits >= 1 && splits <= 65535, "conv2d_wgrad: splits=%d out of range", splits);
+  const int esz = dtype == MI355_BF16 ? 2 : 4;
+  const int epc = 16 / esz;
+  MI355_CHECK_ARG(Ci % epc == 0 && Co % epc == 0, "conv2d_wgrad: Ci=%d / Co=%d must be multiples of %d", Ci, Co, epc);
+  MI355_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && (ldx * esz) % 16 == 0 && (ldy * esz) % 16 == 0,
+                  "conv2d_wgrad: pointers / channel strides must be 16-byte aligned");
+  MI355_CHECK_ARG((long long)N * Ho * Wo < (1ll << 31) && (long long)N * Hi * Wi < (1ll << 31),
+                  "conv2d_wgrad: pixel count overflows int32");
+  WgradArgs a;
+  a.x = x; a.dy = dy; a.ws = ws;
+  a.N = N; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.ldx = ldx;
+  a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.ldy = ldy;
+  a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.up = up ? 1 : 0;
+  a.M = N * Ho * Wo;
+  a.Hlog = up ? 2 * Hi : Hi;
+  a.Wlog = up ? 2 * Wi : Wi;
+  a.chunk = ceil_div(ceil_div(a.M, splits), 32) * 32;
+  if (dtype == MI355_BF16) return wgrad_launch<bf16_t>(a, splits, (hipStream_t)s);
+  if (dtype == MI355_F32) return wgrad_launch<float>(a, splits, (hipStream_t)s);
+  MI355_FAIL(MI355_ERR_UNSUPPORTED, "conv2d_wgrad: unknown dtype %d", dtype);
+}
+
+// dw[co][ci][kh][kw] (or [ci][co][kh][kw] when transposed) = beta*dw + sum_s ws[s][co][tap][ci]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, float* __restrict__ dw, int Co, int Ci,
+                                    int Ci_real, int taps, int transposed, float beta) {
+  const size_t total = (size_t)Co * taps * Ci;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int ci = idx % Ci;
+  const int tap = (idx / Ci) % taps;
+  const int co = idx / ((size_t)Ci * taps);
+  if (ci >= Ci_real) return;
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += ws[(size_t)k * total + idx];
+  const size_t o = transposed ? ((size_t)ci * Co + co) * taps + tap : ((size_t)co * Ci_real + ci) * taps + tap;
+  dw[o] = (beta != 0.f ? beta * dw[o] : 0.f) + s;
+}
+
+extern "C" int mi355_conv2d_wgrad_reduce(const float* ws, int splits, float* dw, int Co, int Ci, int Ci_real, int KH,
+                                         int KW, int transposed, float beta, mi355_stream_t s) {
+  MI355_CHECK_ARG(ws && dw && splits >= 1, "conv2d_wgrad_reduce: bad arguments");
+  const size_t total = (size_t)Co * KH * KW * Ci;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)s, ws, splits, dw, Co, Ci,
+                     Ci_real, KH * KW, transposed, beta);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}

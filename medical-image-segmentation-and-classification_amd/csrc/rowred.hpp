@@ -1,0 +1,150 @@
+// Column (per-channel) reduction skeleton over an NHWC tensor viewed as [M rows][C channels].
+//
+// HBM-bound by construction: every lane moves 16 contiguous bytes per access, consecutive
+// lanes cover consecutive channel chunks of one pixel row (full-line coalescing), each
+// workgroup walks a contiguous band of rows, keeps its per-channel partial sums in registers,
+// folds the row-parallel thread groups through LDS once, and writes ONE partial row per
+// workgroup:  partial[(block*NQ + q)*C + c].  A tiny finalize kernel sums the partials in a
+// fixed order (deterministic, no float atomics).
+#pragma once
+#include "common.hpp"
+
+#define MI355_RR_MAX_BLOCKS 1024
+
+static inline int rowreduce_blocks(long long M) {
+  long long b = (M + 63) / 64;
+  if (b < 1) b = 1;
+  if (b > MI355_RR_MAX_BLOCKS) b = MI355_RR_MAX_BLOCKS;
+  return (int)b;
+}
+
+struct RowRedGeom {
+  long long M;
+  int C;
+  int rows_per_block;
+  int tpr;   // threads per row (<= 256)
+  int rp;    // rows walked in parallel by one block
+};
+
+template <typename T>
+static inline RowRedGeom rowred_geom(long long M, int C, int nblocks) {
+  RowRedGeom g;
+  const int epc = 16 / (int)sizeof(T);
+  const int cp = C / epc;
+  g.M = M;
+  g.C = C;
+  g.rows_per_block = (int)((M + nblocks - 1) / nblocks);
+  g.tpr = cp < 256 ? cp : 256;
+  g.rp = 256 / g.tpr;
+  return g;
+}
+
+// Op contract:
+//   static constexpr int NQ;                       number of reduced quantities
+//   typedef ... Acc;                               float or double
+//   __device__ void load_cols(int c0);             (optional per-chunk constants)
+//   __device__ void apply(size_t row, int c0, Acc (&acc)[NQ][EPC]);   may also write outputs
+template <typename T, typename Op>
+__global__ __launch_bounds__(256) void rowred_kernel(Op op, RowRedGeom g, float* __restrict__ partial) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int NQ = Op::NQ;
+  typedef typename Op::Acc Acc;
+  __shared__ Acc red[256 * NQ * EPC / 2 + 1];   // only ty >= 1 rows are staged; sized for the worst case
+  const int tid = threadIdx.x;
+  const int tx = tid % g.tpr, ty = tid / g.tpr;
+  const int chunk = blockIdx.y * 256 + tx;
+  const int c0 = chunk * EPC;
+  const bool active = ty < g.rp && c0 < g.C;
+  Acc acc[NQ][EPC];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[q][e] = 0;
+  if (active) {
+    op.load_cols(c0);
+    const long long r0 = (long long)blockIdx.x * g.rows_per_block;
+    long long r1 = r0 + g.rows_per_block;
+    if (r1 > g.M) r1 = g.M;
+    for (long long r = r0 + ty; r < r1; r += g.rp) op.apply((size_t)r, c0, acc);
+  }
+  // fold the rp row-groups: log-step tree over ty through LDS
+  for (int stride = 1; stride < g.rp; stride <<= 1) {
+    // pairs (ty, ty+stride) with ty % (2*stride) == 0
+    const bool sender = active && (ty % (2 * stride)) == stride;
+    const bool recver = active && (ty % (2 * stride)) == 0 && (ty + stride) < g.rp;
+    __syncthreads();
+    if (sender) {
+      Acc* dst = red + (size_t)(((ty - stride) / (2 * stride)) * g.tpr + tx) * NQ * EPC;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) dst[q * EPC + e] = acc[q][e];
+    }
+    __syncthreads();
+    if (recver) {
+      const Acc* src = red + (size_t)((ty / (2 * stride)) * g.tpr + tx) * NQ * EPC;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[q][e] += src[q * EPC + e];
+    }
+  }
+  if (active && ty == 0 && partial) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) partial[((size_t)blockIdx.x * NQ + q) * g.C + c0 + e] = (float)acc[q][e];
+  }
+}
+
+template <typename T, typename Op>
+static inline int rowred_launch(const Op& op, long long M, int C, float* partial, hipStream_t s) {
+  const int epc = 16 / (int)sizeof(T);
+  if (C % epc != 0) {
+    mi355_set_error("row reduction: C=%d must be a multiple of %d", C, epc);
+    return MI355_ERR_ARG;
+  }
+  const int nb = rowreduce_blocks(M);
+  const RowRedGeom g = rowred_geom<T>(M, C, nb);
+  const int cp = C / epc;
+  dim3 grid(nb, (cp + 255) / 256);
+  hipLaunchKernelGGL((rowred_kernel<T, Op>), grid, dim3(256), 0, s, op, g, partial);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    mi355_set_error("row reduction launch failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  return MI355_OK;
+}
+
+// Elementwise skeleton over [M][C]: Op::apply(row, c0) handles one 16-B chunk.
+template <typename T, typename Op>
+__global__ __launch_bounds__(256) void rowmap_kernel(Op op, long long M, int cp) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  const long long total = M * cp;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / cp;
+    const int c = (int)(i - r * cp);
+    op.apply((size_t)r, c * EPC);
+  }
+}
+
+template <typename T, typename Op>
+static inline int rowmap_launch(const Op& op, long long M, int C, hipStream_t s) {
+  const int epc = 16 / (int)sizeof(T);
+  if (C % epc != 0) {
+    mi355_set_error("elementwise: C=%d must be a multiple of %d", C, epc);
+    return MI355_ERR_ARG;
+  }
+  const int cp = C / epc;
+  long long blocks = (M * cp + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL((rowmap_kernel<T, Op>), dim3((int)blocks), dim3(256), 0, s, op, M, cp);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    mi355_set_error("elementwise launch failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  return MI355_OK;
+}

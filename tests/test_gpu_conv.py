@@ -1,0 +1,155 @@
+"""-m gpu: implicit-GEMM conv (forward, data gradient, ConvTranspose) through the C ABI vs
+torch CPU fp32 (F.conv2d / autograd).  Tolerances: fp32 1e-4 relative-to-max; bf16 compares
+against the CPU result on bf16-rounded operands, 2e-2 relative-to-max (output rounding 2^-8)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import DEV, lib, to_nhwc, from_nhwc, pack_w, rel_err, q, DTYPE_CODE
+
+pytestmark = pytest.mark.gpu
+TOL = {torch.float32: 1e-4, torch.bfloat16: 2e-2}
+
+CASES = [  # N, Ci, H, W, Co, K, stride, pad, up
+    (2, 32, 12, 12, 64, 3, 1, 1, 0),
+    (2, 64, 16, 16, 128, 3, 1, 1, 0),
+    (1, 32, 9, 7, 32, 3, 1, 1, 0),
+    (3, 64, 8, 8, 64, 1, 1, 0, 0),
+    (2, 32, 16, 16, 64, 3, 2, 1, 0),
+    (2, 32, 20, 20, 64, 7, 2, 3, 0),
+    (2, 64, 6, 6, 32, 3, 1, 1, 1),
+    (2, 128, 10, 10, 256, 3, 1, 1, 0),
+    (1, 96, 8, 8, 96, 3, 1, 1, 0),
+]
+
+
+def _conv_ref(x, w, b, s, p, up):
+    if up:
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    return F.conv2d(x, w, b, stride=s, padding=p)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CASES)
+def test_conv_fwd(case, dtype):
+    n, ci, h, w_, co, k, s, p, up = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(n, ci, h, w_, generator=g)
+    w = torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5
+    b = torch.randn(co, generator=g)
+    ref = _conv_ref(q(x, dtype), q(w, dtype), b, s, p, up)
+    ho, wo = ref.shape[2], ref.shape[3]
+    xd = to_nhwc(x, dtype)
+    wf, _ = pack_w(w, dtype)
+    y = torch.full((n, ho, wo, co), float("nan"), dtype=dtype, device=DEV)
+    lib.mi355_conv2d_igemm(xd, wf, b.to(DEV), y, n, h, w_, ci, ci, ho, wo, co, co, k, k, s, 1, -p, 1, up, 0,
+                           DTYPE_CODE[dtype])
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(y), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [c for c in CASES if not c[8]])
+def test_conv_dgrad(case, dtype):
+    n, ci, h, w_, co, k, s, p, up = case
+    g = torch.Generator().manual_seed(7 + hash(case) % 1000)
+    x = torch.randn(n, ci, h, w_, generator=g, requires_grad=True)
+    w = torch.randn(co, ci, k, k, generator=g) / (co * k * k) ** 0.5
+    y = F.conv2d(x, q(w, dtype), None, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(q(dy, dtype))
+    ref = x.grad
+    ho, wo = y.shape[2], y.shape[3]
+    dyd = to_nhwc(dy, dtype)
+    _, wb = pack_w(w, dtype)
+    dx = torch.full((n, h, w_, ci), float("nan"), dtype=dtype, device=DEV)
+    # data gradient = gather over dy with the [Ci][tap][Co] pack: mul=1,kmul=-1,off=+p,div=s
+    lib.mi355_conv2d_igemm(dyd, wb, None, dx, n, ho, wo, co, co, h, w_, ci, ci, k, k, 1, -1, p, s, 0, 0,
+                           DTYPE_CODE[dtype])
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(dx), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_strided_slices_and_accumulate(dtype):
+    """input read from / output written into channel slices of wider buffers; accumulate flag."""
+    n, ci, h, w_, co = 2, 32, 8, 8, 64
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, ci, h, w_, generator=g); w = torch.randn(co, ci, 3, 3, generator=g) * 0.1
+    ref = F.conv2d(q(x, dtype), q(w, dtype), None, padding=1)
+    xin = torch.zeros(n, h, w_, 96, dtype=dtype, device=DEV); xin[..., 64:] = to_nhwc(x, dtype)
+    wf, _ = pack_w(w, dtype)
+    base = torch.randn(n, h, w_, 160, generator=g).to(dtype)
+    out = base.clone().to(DEV)
+    es = out.element_size()
+    lib.mi355_conv2d_igemm(xin.data_ptr() + 64 * es, wf, None, out.data_ptr() + 32 * es, n, h, w_, ci, 96, h, w_, co,
+                           160, 3, 3, 1, 1, -1, 1, 0, 1, DTYPE_CODE[dtype])
+    torch.cuda.synchronize()
+    got = out.float().cpu()
+    exp = base.float().clone(); exp[..., 32:96] += ref.permute(0, 2, 3, 1)
+    assert rel_err(got[..., 32:96], q(exp[..., 32:96], dtype)) < TOL[dtype]
+    assert torch.equal(got[..., :32], base.float()[..., :32]) and torch.equal(got[..., 96:], base.float()[..., 96:])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_transpose_2x2(dtype):
+    n, ci, h, w_, co = 2, 64, 5, 6, 32
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, ci, h, w_, generator=g); w = torch.randn(ci, co, 2, 2, generator=g) * 0.1
+    b = torch.randn(co, generator=g)
+    ref = F.conv_transpose2d(q(x, dtype), q(w, dtype), b, stride=2)
+    wf, _ = pack_w(w, dtype, transposed=True)          # [Co][tap][Ci]
+    y = torch.empty(n, 2 * h, 2 * w_, co, dtype=dtype, device=DEV)
+    lib.mi355_conv2d_igemm(to_nhwc(x, dtype), wf, b.to(DEV), y, n, h, w_, ci, ci, 2 * h, 2 * w_, co, co, 2, 2, 1, -1, 0,
+                           2, 0, 0, DTYPE_CODE[dtype])
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(y), ref) < TOL[dtype]
+
+
+def test_bad_args_raise():
+    x = torch.zeros(1, 4, 4, 24, device=DEV)
+    with pytest.raises(RuntimeError, match="Ci"):
+        lib.mi355_conv2d_igemm(x, x, None, x, 1, 4, 4, 24, 24, 4, 4, 32, 32, 3, 3, 1, 1, -1, 1, 0, 0, 0)
+
+
+WG_CASES = [  # N, Ci, H, W, Co, K, stride, pad, up
+    (2, 32, 12, 12, 64, 3, 1, 1, 0),
+    (2, 64, 16, 16, 128, 3, 1, 1, 0),
+    (1, 32, 9, 7, 32, 3, 1, 1, 0),
+    (3, 64, 8, 8, 64, 1, 1, 0, 0),
+    (2, 32, 16, 16, 64, 3, 2, 1, 0),
+    (2, 32, 20, 20, 64, 7, 2, 3, 0),
+    (2, 64, 6, 6, 32, 3, 1, 1, 1),
+    (2, 128, 10, 10, 256, 3, 1, 1, 0),
+    (4, 128, 24, 24, 128, 3, 1, 1, 0),
+    (1, 96, 8, 8, 160, 3, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", WG_CASES)
+def test_conv_wgrad(case, dtype):
+    n, ci, h, w_, co, k, s, p, up = case
+    g = torch.Generator().manual_seed(13 + hash(case) % 1000)
+    x = torch.randn(n, ci, h, w_, generator=g)
+    w = torch.zeros(co, ci, k, k, requires_grad=True)
+    y = _conv_ref(q(x, dtype), w, None, s, p, up)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(q(dy, dtype))
+    ref = w.grad
+    ho, wo = y.shape[2], y.shape[3]
+    cip = ci + 32 if case == WG_CASES[0] else ci       # exercise a zero-padded input (stem)
+    xd = to_nhwc(x, dtype, cpad=cip)
+    dyd = to_nhwc(dy, dtype)
+    splits = lib.mi355_conv2d_wgrad_splits(n, ho, wo, cip, co, k, k)
+    assert splits >= 1
+    for sp in sorted({splits, 1, 3}):
+        ws = torch.full((sp, co, k * k, cip), float("nan"), device=DEV)
+        lib.mi355_conv2d_wgrad(xd, dyd, ws, sp, n, h, w_, cip, cip, ho, wo, co, co, k, k, s, p, up, DTYPE_CODE[dtype])
+        dw = torch.full((co, ci, k, k), 2.0, device=DEV)
+        lib.mi355_conv2d_wgrad_reduce(ws, sp, dw, co, cip, ci, k, k, 0, 0.0)
+        torch.cuda.synchronize()
+        assert rel_err(dw.cpu(), ref) < TOL[dtype], f"splits={sp}"
+        lib.mi355_conv2d_wgrad_reduce(ws, sp, dw, co, cip, ci, k, k, 0, 1.0)   # beta = 1 accumulates
+        torch.cuda.synchronize()
+        assert rel_err(dw.cpu(), 2 * ref) < TOL[dtype]

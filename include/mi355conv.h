@@ -196,9 +196,9 @@ int mi355_ce_smooth(const float* z, const int64_t* y, float* loss, float* dz, co
 /* sumsq partials of a flat gradient buffer; nblocks = mi355_rowreduce_blocks(n). */
 int mi355_sumsq_partial(const float* g, float* partial, long long n, mi355_stream_t s);
 /* norm[0] = sqrt(sum partial); coef[0] = min(1, max_norm/(norm+1e-6)) (clip_grad_norm_);
- * found_inf[0] = 1 if the norm is not finite. */
+ * found_inf[0] = 1 if the norm is not finite; otherwise step[0] += 1 (the optimiser step counter). */
 int mi355_clip_coef(const float* partial, int nblocks, float max_norm, float inv_scale, float* norm,
-                    float* coef, float* found_inf, mi355_stream_t s);
+                    float* coef, float* found_inf, int32_t* step, mi355_stream_t s);
 /* AdamW, decoupled decay; g is multiplied by coef[0]*inv_scale first; skipped when found_inf[0] != 0.
  * step_count is read from device memory (graph-capturable). */
 int mi355_adamw(float* p, const float* g, float* m, float* v, long long n, const float* lr, float beta1,

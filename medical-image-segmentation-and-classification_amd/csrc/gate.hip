@@ -1,0 +1,248 @@
+// Attention-gate tail and single-output 1x1 convolutions (Co == 1): per-pixel dot products.
+// These are HBM-bound row reductions, not GEMMs: TPR lanes (a power of two <= 64) share one pixel
+// row, each lane moving 16-B channel chunks, folded with xor-shuffles; per-workgroup (sum, sum^2)
+// partials feed the one-channel BatchNorm that follows psi (AttentionUNet.py:40-44).
+#include "rowred.hpp"
+
+#define ROWDOT_MAXCH 4
+
+static inline int pow2_tpr(int cp) {
+  int t = 1;
+  while (t < cp && t < 64) t <<= 1;
+  return t;
+}
+
+__device__ __forceinline__ float seg_sum(float v, int tpr) {
+  for (int o = tpr >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-level sum of two doubles -> partial[blk*2 + {0,1}]
+__device__ __forceinline__ void block_pair_sum(double s0, double s1, float* partial) {
+  __shared__ double red[8];
+  s0 = wave_sum_d(s0);
+  s1 = wave_sum_d(s1);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[wave * 2] = s0;
+    red[wave * 2 + 1] = s1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && partial) {
+    partial[blockIdx.x * 2 + 0] = (float)(red[0] + red[2] + red[4] + red[6]);
+    partial[blockIdx.x * 2 + 1] = (float)(red[1] + red[3] + red[5] + red[7]);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rowdot_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                         const float* __restrict__ b, float* __restrict__ z,
+                                                         float* __restrict__ partial, long long M, int C,
+                                                         int rows_per_block, int tpr) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  const int cp = C / EPC;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % tpr, rsub = lane / tpr, rpw = 64 / tpr;
+  float wr[ROWDOT_MAXCH][EPC];
+#pragma unroll
+  for (int k = 0; k < ROWDOT_MAXCH; ++k) {
+    const int ck = sub + k * tpr;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) wr[k][e] = ck < cp ? w[ck * EPC + e] : 0.f;
+  }
+  const float bias = b ? b[0] : 0.f;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = min(M, r0 + rows_per_block);
+  double s0 = 0, s1 = 0;
+  for (long long base = r0 + wave * rpw; base < r1; base += 4 * rpw) {
+    const long long r = base + rsub;
+    float acc = 0.f;
+    if (r < r1) {
+#pragma unroll
+      for (int k = 0; k < ROWDOT_MAXCH; ++k) {
+        const int ck = sub + k * tpr;
+        if (ck < cp) {
+          const Vec16<T> v = ld16<T>(x + (size_t)r * ldx + ck * EPC);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) acc += to_f32<T>(v.v[e]) * wr[k][e];
+        }
+      }
+    }
+    acc = seg_sum(acc, tpr);
+    if (r < r1 && sub == 0) {
+      const float zz = acc + bias;
+      z[r] = zz;
+      s0 += zz;
+      s1 += (double)zz * zz;
+    }
+  }
+  block_pair_sum(s0, s1, partial);
+}
+
+extern "C" int mi355_rowdot_fwd(const void* x, int ldx, const float* w, const float* b, float* z, float* partial,
+                                long long M, int C, int dtype, mi355_stream_t s) {
+  MI355_CHECK_ARG(x && w && z, "rowdot_fwd: null pointer");
+  const int epc = dtype == MI355_BF16 ? 8 : 4;
+  MI355_CHECK_ARG(C % epc == 0 && C / epc <= 64 * ROWDOT_MAXCH, "rowdot_fwd: unsupported C=%d", C);
+  const int nb = rowreduce_blocks(M);
+  const int rpb = (int)((M + nb - 1) / nb);
+  const int tpr = pow2_tpr(C / epc);
+  if (dtype == MI355_BF16)
+    hipLaunchKernelGGL((rowdot_fwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, ldx, w, b, z, partial,
+                       M, C, rpb, tpr);
+  else
+    hipLaunchKernelGGL((rowdot_fwd_kernel<float>), dim3(nb), dim3(256), 0, (hipStream_t)s, (const float*)x, ldx, w, b, z, partial, M,
+                       C, rpb, tpr);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+// dx[m][c] = dz[m]*w[c]*(mask ? x[m][c] > 0 : 1);  partial: q0 = sum_m dz[m]*x[m][c], q1 = sum_m dz[m]
+template <typename T> struct RowdotBwdOp {
+  static constexpr int NQ = 2;
+  typedef float Acc;
+  static constexpr int EPC = 16 / (int)sizeof(T);
+  const float* dz; const T* x; int ldx; const float* w; T* dx; int lddx; int mask;
+  float wr[EPC];
+  __device__ void load_cols(int c0) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) wr[e] = w[c0 + e];
+  }
+  __device__ void apply(size_t row, int c0, Acc (&acc)[NQ][EPC]) const {
+    const float d = dz[row];
+    const Vec16<T> v = ld16<T>(x + row * ldx + c0);
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const float xv = to_f32<T>(v.v[e]);
+      acc[0][e] += d * xv;
+      acc[1][e] += d;
+      o.v[e] = from_f32<T>((mask && !(xv > 0.f)) ? 0.f : d * wr[e]);
+    }
+    if (dx) st16<T>(dx + row * lddx + c0, o);
+  }
+};
+
+extern "C" int mi355_rowdot_bwd(const float* dz, const void* x, int ldx, const float* w, void* dx, int lddx,
+                                float* partial, long long M, int C, int relu_mask, int dtype, mi355_stream_t s) {
+  MI355_CHECK_ARG(dz && x && w && partial, "rowdot_bwd: null pointer");
+  if (dtype == MI355_BF16) {
+    RowdotBwdOp<bf16_t> op{dz, (const bf16_t*)x, ldx, w, (bf16_t*)dx, lddx, relu_mask};
+    return rowred_launch<bf16_t>(op, M, C, partial, (hipStream_t)s);
+  }
+  RowdotBwdOp<float> op{dz, (const float*)x, ldx, w, (float*)dx, lddx, relu_mask};
+  return rowred_launch<float>(op, M, C, partial, (hipStream_t)s);
+}
+
+// ---- x * sigmoid(bn1(z)) ---------------------------------------------------------------------------------
+template <typename T> struct GateMulOp {
+  static constexpr int EPC = 16 / (int)sizeof(T);
+  const T* x; int ldx; const float* z; const float* scale; const float* shift; T* y; int ldy;
+  __device__ void apply(size_t row, int c0) const {
+    const float psi = 1.f / (1.f + __expf(-(z[row] * scale[0] + shift[0])));
+    Vec16<T> v = ld16<T>(x + row * ldx + c0);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) v.v[e] = from_f32<T>(to_f32<T>(v.v[e]) * psi);
+    st16<T>(y + row * ldy + c0, v);
+  }
+};
+
+extern "C" int mi355_gate_mul_fwd(const void* x, int ldx, const float* z, const float* scale, const float* shift, void* y,
+                                  int ldy, long long M, int C, int dtype, mi355_stream_t s) {
+  MI355_CHECK_ARG(x && z && scale && shift && y, "gate_mul_fwd: null pointer");
+  if (dtype == MI355_BF16) {
+    GateMulOp<bf16_t> op{(const bf16_t*)x, ldx, z, scale, shift, (bf16_t*)y, ldy};
+    return rowmap_launch<bf16_t>(op, M, C, (hipStream_t)s);
+  }
+  GateMulOp<float> op{(const float*)x, ldx, z, scale, shift, (float*)y, ldy};
+  return rowmap_launch<float>(op, M, C, (hipStream_t)s);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gate_mul_bwd_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ x, int ldx,
+                                                           const float* __restrict__ z, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, T* __restrict__ dx, int lddx,
+                                                           int accumulate, float* __restrict__ dzn,
+                                                           float* __restrict__ partial, long long M, int C, int rows_per_block,
+                                                           int tpr) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  const int cp = C / EPC;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % tpr, rsub = lane / tpr, rpw = 64 / tpr;
+  const float sc = scale[0], sh = shift[0], mu = mean[0], is = invstd[0];
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = min(M, r0 + rows_per_block);
+  double s0 = 0, s1 = 0;
+  for (long long base = r0 + wave * rpw; base < r1; base += 4 * rpw) {
+    const long long r = base + rsub;
+    float acc = 0.f, psi = 0.f, zz = 0.f;
+    if (r < r1) {
+      zz = z[r];
+      psi = 1.f / (1.f + __expf(-(zz * sc + sh)));
+      for (int ck = sub; ck < cp; ck += tpr) {
+        const Vec16<T> g = ld16<T>(dy + (size_t)r * lddy + ck * EPC);
+        const Vec16<T> xv = ld16<T>(x + (size_t)r * ldx + ck * EPC);
+        T* o = dx + (size_t)r * lddx + ck * EPC;
+        Vec16<T> ov;
+        if (accumulate) ov = ld16<T>(o);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          const float gg = to_f32<T>(g.v[e]);
+          acc += gg * to_f32<T>(xv.v[e]);
+          const float d = gg * psi;
+          ov.v[e] = from_f32<T>(accumulate ? to_f32<T>(ov.v[e]) + d : d);
+        }
+        st16<T>(o, ov);
+      }
+    }
+    acc = seg_sum(acc, tpr);
+    if (r < r1 && sub == 0) {
+      const float d = acc * psi * (1.f - psi);
+      dzn[r] = d;
+      s0 += d;
+      s1 += (double)d * ((zz - mu) * is);
+    }
+  }
+  block_pair_sum(s0, s1, partial);
+}
+
+extern "C" int mi355_gate_mul_bwd(const void* dy, int lddy, const void* x, int ldx, const float* z, const float* scale,
+                                  const float* shift, const float* mean, const float* invstd, void* dx, int lddx,
+                                  int accumulate, float* dzn, float* partial, long long M, int C, int dtype,
+                                  mi355_stream_t s) {
+  MI355_CHECK_ARG(dy && x && z && scale && shift && mean && invstd && dx && dzn && partial, "gate_mul_bwd: null pointer");
+  const int epc = dtype == MI355_BF16 ? 8 : 4;
+  MI355_CHECK_ARG(C % epc == 0, "gate_mul_bwd: C=%d must be a multiple of %d", C, epc);
+  const int nb = rowreduce_blocks(M);
+  const int rpb = (int)((M + nb - 1) / nb);
+  const int tpr = pow2_tpr(C / epc);
+  if (dtype == MI355_BF16)
+    hipLaunchKernelGGL((gate_mul_bwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, (hipStream_t)s, (const bf16_t*)dy, lddy,
+                       (const bf16_t*)x, ldx, z, scale, shift, mean, invstd, (bf16_t*)dx, lddx, accumulate, dzn, partial, M, C, rpb,
+                       tpr);
+  else
+    hipLaunchKernelGGL((gate_mul_bwd_kernel<float>), dim3(nb), dim3(256), 0, (hipStream_t)s, (const float*)dy, lddy, (const float*)x,
+                       ldx, z, scale, shift, mean, invstd, (float*)dx, lddx, accumulate, dzn, partial, M, C, rpb, tpr);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+__global__ void bn1_bwd_apply_kernel(const float* __restrict__ dzn, const float* __restrict__ z, const float* gamma,
+                                     const float* mean, const float* invstd, const float* sums, float* __restrict__ dz,
+                                     long long M) {
+  const float is = invstd[0], mu = mean[0], gi = gamma[0] * is;
+  const float k0 = sums[0] / (float)M, k1 = sums[1] / (float)M;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (long long)gridDim.x * blockDim.x)
+    dz[i] = gi * (dzn[i] - k0 - (z[i] - mu) * is * k1);
+}
+
+extern "C" int mi355_bn1_bwd_apply(const float* dzn, const float* z, const float* gamma, const float* mean,
+                                   const float* invstd, const float* sums, float* dz, long long M, mi355_stream_t s) {
+  MI355_CHECK_ARG(dzn && z && gamma && mean && invstd && sums && dz, "bn1_bwd_apply: null pointer");
+  long long blocks = (M + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(bn1_bwd_apply_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)s, dzn, z, gamma, mean, invstd, sums, dz, M);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}

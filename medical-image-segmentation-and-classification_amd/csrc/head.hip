@@ -1,0 +1,194 @@
+// Classifier heads: global max/avg pooling, tiny fp32 Linear layers, dropout (ResNet.py:112-115,
+// VGG.py:103-122, helpers.py:124-143).  M = batch is tiny here, so these are latency-bound VALU
+// kernels; they exist so that the whole step runs on the library without torch math.
+#include "common.hpp"
+
+// one workgroup per (n, 64-channel group): 4 waves split the HW positions, lanes own channels
+template <typename T>
+__global__ __launch_bounds__(256) void global_pool_fwd_kernel(const T* __restrict__ x, int ldx, float* __restrict__ y,
+                                                              int32_t* __restrict__ argmax, int HW, int C, int is_max) {
+  __shared__ float sv[4][64];
+  __shared__ int si[4][64];
+  const int n = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6;
+  float best = is_max ? -INFINITY : 0.f;
+  int bi = 0;
+  if (c < C) {
+    for (int p = wave; p < HW; p += 4) {
+      const float v = to_f32<T>(x[((size_t)n * HW + p) * ldx + c]);
+      if (is_max) {
+        if (v > best) { best = v; bi = p; }
+      } else {
+        best += v;
+      }
+    }
+  }
+  sv[wave][threadIdx.x & 63] = best;
+  si[wave][threadIdx.x & 63] = bi;
+  __syncthreads();
+  if (wave == 0 && c < C) {
+    float r = sv[0][threadIdx.x];
+    int ri = si[0][threadIdx.x];
+    for (int w = 1; w < 4; ++w) {
+      const float v = sv[w][threadIdx.x];
+      const int vi = si[w][threadIdx.x];
+      if (is_max) {
+        if (v > r || (v == r && vi < ri)) { r = v; ri = vi; }   // first maximum in scan order
+      } else {
+        r += v;
+      }
+    }
+    y[(size_t)n * C + c] = is_max ? r : r / (float)HW;
+    if (argmax) argmax[(size_t)n * C + c] = ri;
+  }
+}
+
+extern "C" int mi355_global_pool_fwd(const void* x, int ldx, float* y, int32_t* argmax, int N, int HW, int C, int is_max,
+                                     int dtype, mi355_stream_t s) {
+  MI355_CHECK_ARG(x && y && (!is_max || argmax), "global_pool_fwd: null pointer");
+  dim3 grid(ceil_div(C, 64), N);
+  if (dtype == MI355_BF16)
+    hipLaunchKernelGGL((global_pool_fwd_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, ldx, y, argmax, HW, C,
+                       is_max);
+  else
+    hipLaunchKernelGGL((global_pool_fwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)s, (const float*)x, ldx, y, argmax, HW, C,
+                       is_max);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+template <typename T>
+__global__ void global_pool_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ argmax, T* __restrict__ dx,
+                                       int lddx, int HW, int C, int is_max, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long long np = i / C;
+    const int p = (int)(np % HW);
+    const long long n = np / HW;
+    const float g = dy[n * C + c];
+    const float v = is_max ? (argmax[n * C + c] == p ? g : 0.f) : g / (float)HW;
+    dx[(size_t)np * lddx + c] = from_f32<T>(v);
+  }
+}
+
+extern "C" int mi355_global_pool_bwd(const float* dy, const int32_t* argmax, void* dx, int lddx, int N, int HW, int C,
+                                     int is_max, int dtype, mi355_stream_t s) {
+  MI355_CHECK_ARG(dy && dx && (!is_max || argmax), "global_pool_bwd: null pointer");
+  const long long total = (long long)N * HW * C;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (dtype == MI355_BF16)
+    hipLaunchKernelGGL((global_pool_bwd_kernel<bf16_t>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, dy, argmax, (bf16_t*)dx,
+                       lddx, HW, C, is_max, total);
+  else
+    hipLaunchKernelGGL((global_pool_bwd_kernel<float>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, dy, argmax, (float*)dx, lddx,
+                       HW, C, is_max, total);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+// ---- Linear (fp32): one wave per output element -------------------------------------------------------
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int B, int I,
+                                                         int O, int relu) {
+  const int gw = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (gw >= B * O) return;
+  const int b = gw / O, o = gw - b * O;
+  float acc = 0.f;
+  for (int i = lane; i < I; i += 64) acc += x[(size_t)b * I + i] * w[(size_t)o * I + i];
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    acc += bias ? bias[o] : 0.f;
+    y[gw] = relu ? fmaxf(acc, 0.f) : acc;
+  }
+}
+
+extern "C" int mi355_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int I, int O, int relu,
+                                mi355_stream_t s) {
+  MI355_CHECK_ARG(x && w && y, "linear_fwd: null pointer");
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3(ceil_div((long long)B * O, 4)), dim3(256), 0, (hipStream_t)s, x, w, bias, y, B, I, O,
+                     relu);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+// g = dy * (relu ? y > 0 : 1);  dx[b][i] = sum_o g[b][o] w[o][i];  dw[o][i] = beta*dw + sum_b g[b][o] x[b][i]
+__global__ void linear_bwd_dx_kernel(const float* __restrict__ w, const float* __restrict__ y, const float* __restrict__ dy,
+                                     float* __restrict__ dx, int B, int I, int O, int relu) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * I) return;
+  const int b = idx / I, i = idx - b * I;
+  float acc = 0.f;
+  for (int o = 0; o < O; ++o) {
+    float g = dy[(size_t)b * O + o];
+    if (relu && !(y[(size_t)b * O + o] > 0.f)) g = 0.f;
+    acc += g * w[(size_t)o * I + i];
+  }
+  dx[idx] = acc;
+}
+
+__global__ void linear_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+                                     float* __restrict__ dw, float* __restrict__ db, int B, int I, int O, int relu,
+                                     float beta) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= O * I) return;
+  const int o = idx / I, i = idx - o * I;
+  float acc = 0.f, accb = 0.f;
+  for (int b = 0; b < B; ++b) {
+    float g = dy[(size_t)b * O + o];
+    if (relu && !(y[(size_t)b * O + o] > 0.f)) g = 0.f;
+    acc += g * x[(size_t)b * I + i];
+    accb += g;
+  }
+  dw[idx] = (beta != 0.f ? beta * dw[idx] : 0.f) + acc;
+  if (db && i == 0) db[o] = (beta != 0.f ? beta * db[o] : 0.f) + accb;
+}
+
+extern "C" int mi355_linear_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw,
+                                float* db, int B, int I, int O, int relu, float beta, mi355_stream_t s) {
+  MI355_CHECK_ARG(x && w && dy && (!relu || y), "linear_bwd: null pointer");
+  if (dx) hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(ceil_div((long long)B * I, 256)), dim3(256), 0, (hipStream_t)s, w, y, dy, dx, B, I, O, relu);
+  if (dw) hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(ceil_div((long long)O * I, 256)), dim3(256), 0, (hipStream_t)s, x, y, dy, dw, db, B, I, O, relu, beta);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+// ---- dropout ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix32(uint64_t k) {   // splitmix64 finaliser
+  k += 0x9E3779B97F4A7C15ull;
+  k = (k ^ (k >> 30)) * 0xBF58476D1CE4E5B9ull;
+  k = (k ^ (k >> 27)) * 0x94D049BB133111EBull;
+  return (uint32_t)((k ^ (k >> 31)) >> 32);
+}
+
+__global__ void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ mask, long long n,
+                                   float p, uint64_t seed) {
+  const float scale = p < 1.f ? 1.f / (1.f - p) : 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float u = (float)(mix32(seed * 0x100000001B3ull + (uint64_t)i) >> 8) * (1.0f / 16777216.0f);
+    const uint8_t keep = u >= p;
+    mask[i] = keep;
+    y[i] = keep ? x[i] * scale : 0.f;
+  }
+}
+
+__global__ void dropout_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ mask, float* __restrict__ dx,
+                                   long long n, float p) {
+  const float scale = p < 1.f ? 1.f / (1.f - p) : 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    dx[i] = mask[i] ? dy[i] * scale : 0.f;
+}
+
+extern "C" int mi355_dropout_fwd(const float* x, float* y, uint8_t* mask, long long n, float p, uint64_t seed,
+                                 mi355_stream_t s) {
+  MI355_CHECK_ARG(x && y && mask && p >= 0.f && p <= 1.f, "dropout_fwd: bad arguments");
+  hipLaunchKernelGGL(dropout_fwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)s, x, y, mask, n, p, seed);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+extern "C" int mi355_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, long long n, float p, mi355_stream_t s) {
+  MI355_CHECK_ARG(dy && mask && dx, "dropout_bwd: null pointer");
+  hipLaunchKernelGGL(dropout_bwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)s, dy, mask, dx, n, p);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}

@@ -1,0 +1,221 @@
+// Losses, gradient-norm clipping, fused AdamW on flat fp32 buffers, segmentation metric counters.
+// (utils/helpers.py:244-246, 251, 332-336; utils/tester.py:92-193.)  Everything the optimiser needs
+// (lr, step, clip coefficient, inf flag) lives in device memory so a captured hipGraph replays it.
+#include "rowred.hpp"
+
+__device__ __forceinline__ float block_sum_f(float v) {
+  __shared__ float red[4];
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const float r = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  return r;
+}
+
+// ---- BCEWithLogits (mean) ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict__ z, const float* __restrict__ t,
+                                                         float* __restrict__ loss, float* __restrict__ dz,
+                                                         const float* __restrict__ gscale, long long n) {
+  const float gs = (gscale ? gscale[0] : 1.f) / (float)n;
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float x = z[i], y = t[i];
+    acc += fmaxf(x, 0.f) - x * y + log1pf(__expf(-fabsf(x)));
+    if (dz) dz[i] = (1.f / (1.f + __expf(-x)) - y) * gs;
+  }
+  acc = block_sum_f(acc);
+  if (threadIdx.x == 0) atomicAdd(loss, acc / (float)n);
+}
+
+extern "C" int mi355_bce_logits(const float* z, const float* t, float* loss, float* dz, const float* gscale, long long n,
+                                mi355_stream_t s) {
+  MI355_CHECK_ARG(z && t && loss && n > 0, "bce_logits: bad arguments");
+  hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)s);
+  if (e != hipSuccess) MI355_FAIL((int)e, "bce_logits: memset failed: %s", hipGetErrorString(e));
+  long long blocks = (n + 1023) / 1024;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(bce_logits_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)s, z, t, loss, dz, gscale, n);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+// ---- CrossEntropy with label smoothing (one workgroup; B*C is tiny) ----------------------------------------
+__global__ __launch_bounds__(256) void ce_smooth_kernel(const float* __restrict__ z, const int64_t* __restrict__ y,
+                                                        float* __restrict__ loss, float* __restrict__ dz,
+                                                        const float* __restrict__ gscale, int B, int C, float sm) {
+  const float gs = (gscale ? gscale[0] : 1.f) / (float)B;
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float* row = z + (size_t)b * C;
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, row[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += __expf(row[c] - mx);
+    const float lse = mx + __logf(se);
+    const int lab = (int)y[b];
+    float sum_logp = 0.f;
+    for (int c = 0; c < C; ++c) sum_logp += row[c] - lse;
+    acc += -(1.f - sm) * (row[lab] - lse) - sm * sum_logp / (float)C;
+    if (dz)
+      for (int c = 0; c < C; ++c) {
+        const float p = __expf(row[c] - lse);
+        const float tgt = (1.f - sm) * (c == lab ? 1.f : 0.f) + sm / (float)C;
+        dz[(size_t)b * C + c] = (p - tgt) * gs;
+      }
+  }
+  acc = block_sum_f(acc);
+  if (threadIdx.x == 0) loss[0] = acc / (float)B;
+}
+
+extern "C" int mi355_ce_smooth(const float* z, const int64_t* y, float* loss, float* dz, const float* gscale, int B, int C,
+                               float smoothing, mi355_stream_t s) {
+  MI355_CHECK_ARG(z && y && loss && B > 0 && C > 0, "ce_smooth: bad arguments");
+  hipLaunchKernelGGL(ce_smooth_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, z, y, loss, dz, gscale, B, C, smoothing);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+// ---- gradient norm + clip coefficient ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, float* __restrict__ partial, long long n) {
+  double acc = 0;
+  const long long n4 = n >> 2;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 v = g4[i];
+    acc += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const float v = g[(n4 << 2) + threadIdx.x];
+    acc += (double)v * v;
+  }
+  __shared__ double red[4];
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (float)(red[0] + red[1] + red[2] + red[3]);
+}
+
+extern "C" int mi355_sumsq_partial(const float* g, float* partial, long long n, mi355_stream_t s) {
+  MI355_CHECK_ARG(g && partial && ((uintptr_t)g % 16) == 0, "sumsq_partial: bad arguments");
+  hipLaunchKernelGGL(sumsq_kernel, dim3(rowreduce_blocks(n)), dim3(256), 0, (hipStream_t)s, g, partial, n);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+__global__ void clip_coef_kernel(const float* __restrict__ partial, int nblocks, float max_norm, float inv_scale,
+                                 float* norm, float* coef, float* found_inf, int32_t* step) {
+  double acc = 0;
+  for (int b = threadIdx.x; b < nblocks; b += 64) acc += (double)partial[b];
+  acc = wave_sum_d(acc);
+  if (threadIdx.x == 0) {
+    const float nrm = (float)sqrt(acc) * inv_scale;
+    const bool bad = !isfinite(nrm);
+    norm[0] = nrm;
+    coef[0] = max_norm > 0.f ? fminf(1.f, max_norm / (nrm + 1e-6f)) : 1.f;
+    if (found_inf) found_inf[0] = bad ? 1.f : 0.f;
+    if (step && !bad) step[0] += 1;
+  }
+}
+
+extern "C" int mi355_clip_coef(const float* partial, int nblocks, float max_norm, float inv_scale, float* norm,
+                               float* coef, float* found_inf, int32_t* step, mi355_stream_t s) {
+  MI355_CHECK_ARG(partial && norm && coef, "clip_coef: null pointer");
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, partial, nblocks, max_norm, inv_scale, norm, coef,
+                     found_inf, step);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+// ---- AdamW (torch.optim.AdamW semantics: decoupled decay, bias-corrected, eps outside sqrt(bc2)) ------------
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long long n, const float* __restrict__ lr_p,
+                                                    float beta1, float beta2, float eps, float wd,
+                                                    const float* __restrict__ coef, float inv_scale,
+                                                    const float* __restrict__ found_inf, const int32_t* __restrict__ step) {
+  if (found_inf && found_inf[0] != 0.f) return;
+  const float lr = lr_p[0];
+  const float gs = (coef ? coef[0] : 1.f) * inv_scale;
+  const float t = (float)step[0];
+  const float bc1 = 1.f - powf(beta1, t);
+  const float bc2s = sqrtf(1.f - powf(beta2, t));
+  const float step_size = lr / bc1;
+  const float decay = 1.f - lr * wd;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float gg = g[i] * gs;
+    float pp = p[i] * decay;
+    const float mm = beta1 * m[i] + (1.f - beta1) * gg;
+    const float vv = beta2 * v[i] + (1.f - beta2) * gg * gg;
+    pp -= step_size * mm / (sqrtf(vv) / bc2s + eps);
+    p[i] = pp;
+    m[i] = mm;
+    v[i] = vv;
+  }
+}
+
+extern "C" int mi355_adamw(float* p, const float* g, float* m, float* v, long long n, const float* lr, float beta1,
+                           float beta2, float eps, float wd, const float* coef, float inv_scale, const float* found_inf,
+                           const int32_t* step, mi355_stream_t s) {
+  MI355_CHECK_ARG(p && g && m && v && lr && step && n > 0, "adamw: bad arguments");
+  long long blocks = (n + 255) / 256;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  hipLaunchKernelGGL(adamw_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)s, p, g, m, v, n, lr, beta1, beta2, eps, wd, coef,
+                     inv_scale, found_inf, step);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+__global__ void fill_kernel(float* p, float v, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+extern "C" int mi355_fill_f32(float* p, float v, long long n, mi355_stream_t s) {
+  MI355_CHECK_ARG(p && n >= 0, "fill_f32: bad arguments");
+  if (n == 0) return MI355_OK;
+  long long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(fill_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)s, p, v, n);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+// ---- segmentation counters ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void seg_counts_kernel(const float* __restrict__ pr, const float* __restrict__ tg,
+                                                         float* __restrict__ counts, long long per, int is_logit, float thr) {
+  const int b = blockIdx.y;
+  const float* p = pr + (size_t)b * per;
+  const float* t = tg + (size_t)b * per;
+  float tp = 0, pp = 0, tt = 0, eq = 0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long long)gridDim.x * 256) {
+    float v = p[i];
+    if (is_logit) v = 1.f / (1.f + __expf(-v));
+    const bool pb = v > thr, tb = t[i] > thr;
+    tp += (pb && tb);
+    pp += pb;
+    tt += tb;
+    eq += (pb == tb);
+  }
+  tp = block_sum_f(tp);
+  pp = block_sum_f(pp);
+  tt = block_sum_f(tt);
+  eq = block_sum_f(eq);
+  if (threadIdx.x == 0) {
+    atomicAdd(counts + b * 4 + 0, tp);
+    atomicAdd(counts + b * 4 + 1, pp);
+    atomicAdd(counts + b * 4 + 2, tt);
+    atomicAdd(counts + b * 4 + 3, eq);
+  }
+}
+
+extern "C" int mi355_seg_counts(const float* prob_or_logit, const float* target, float* counts, int B, long long per,
+                                int is_logit, float thr, mi355_stream_t s) {
+  MI355_CHECK_ARG(prob_or_logit && target && counts && B > 0 && per > 0, "seg_counts: bad arguments");
+  hipError_t e = hipMemsetAsync(counts, 0, sizeof(float) * 4 * B, (hipStream_t)s);
+  if (e != hipSuccess) MI355_FAIL((int)e, "seg_counts: memset failed: %s", hipGetErrorString(e));
+  long long bx = (per + 2047) / 2048;
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(seg_counts_kernel, dim3((int)bx, B), dim3(256), 0, (hipStream_t)s, prob_or_logit, target, counts, per, is_logit,
+                     thr);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}

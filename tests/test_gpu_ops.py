@@ -1,0 +1,321 @@
+"""-m gpu: every non-GEMM launcher of the C ABI against torch CPU fp32 (autograd where a
+backward is involved).  fp32 tolerance 1e-5..1e-4 relative-to-max; bf16 inputs are rounded to
+bf16 before the CPU reference, outputs allowed 2^-7 relative (one bf16 rounding of the result)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import DEV, lib, to_nhwc, from_nhwc, pack_w, rel_err, q, DTYPE_CODE
+
+pytestmark = pytest.mark.gpu
+DT = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 2e-5, torch.bfloat16: 1.2e-2}
+
+
+def dev(t):
+    return t.to(DEV)
+
+
+def _partials(m, c, nq=2):
+    nb = lib.mi355_rowreduce_blocks(m)
+    return nb, torch.full((nb * nq * c,), float("nan"), device=DEV)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(2, 32, 9, 7), (3, 64, 16, 16), (2, 96, 5, 5), (1, 1024, 4, 4), (4, 8, 40, 40)])
+def test_bn_forward_train(shape, dtype):
+    n, c, h, w = shape
+    if dtype == torch.float32 and c % 4 or dtype == torch.bfloat16 and c % 8:
+        pytest.skip("chunk multiple")
+    g = torch.Generator().manual_seed(c)
+    x = q(torch.randn(shape, generator=g) * 2 + 0.5, dtype)
+    gamma = torch.rand(c, generator=g) + 0.5; beta = torch.randn(c, generator=g)
+    rm = torch.randn(c, generator=g) * 0.1; rv = torch.rand(c, generator=g) + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    ref = F.relu(F.batch_norm(x, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5))
+    m = n * h * w
+    xd = to_nhwc(x, dtype)
+    nb, part = _partials(m, c)
+    lib.mi355_bn_stats(xd, part, m, c, c, DTYPE_CODE[dtype])
+    rmd, rvd, nbt = dev(rm), dev(rv), torch.zeros((), dtype=torch.int64, device=DEV)
+    sc, sh, mu, isd = (torch.empty(c, device=DEV) for _ in range(4))
+    lib.mi355_bn_finalize(part, nb, m, c, dev(gamma), dev(beta), rmd, rvd, nbt, 0.1, 1e-5, sc, sh, mu, isd)
+    y = torch.empty_like(xd)
+    lib.mi355_bn_act(xd, c, sc, sh, None, 0, None, None, None, 0, y, c, m, c, 1, DTYPE_CODE[dtype])
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(y), ref) < TOL[dtype]
+    assert rel_err(rmd.cpu(), rm_ref) < 1e-5 and rel_err(rvd.cpu(), rv_ref) < 1e-5 and int(nbt) == 1
+    assert rel_err(mu.cpu(), x.mean((0, 2, 3))) < 1e-5
+    assert rel_err(isd.cpu(), 1 / torch.sqrt(x.var((0, 2, 3), unbiased=False) + 1e-5)) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("act,with_res", [(1, False), (0, False), (1, True)])
+def test_bn_backward(dtype, act, with_res):
+    n, c, h, w = 3, 64, 10, 6
+    g = torch.Generator().manual_seed(5 + act)
+    x = q(torch.randn(n, c, h, w, generator=g) * 1.5 + 0.3, dtype).requires_grad_(True)
+    res = q(torch.randn(n, c, h, w, generator=g), dtype).requires_grad_(True)
+    gamma = (torch.rand(c, generator=g) + 0.5).requires_grad_(True); beta = torch.randn(c, generator=g).requires_grad_(True)
+    yb = F.batch_norm(x, None, None, gamma, beta, True, 0.1, 1e-5)
+    y = yb + res if with_res else yb
+    y = F.relu(y) if act else y
+    dy = q(torch.randn(y.shape, generator=g), dtype)
+    y.backward(dy)
+    m = n * h * w
+    xd, dyd, yd = to_nhwc(x.detach(), dtype), to_nhwc(dy, dtype), to_nhwc(y.detach(), dtype)
+    mu = x.detach().mean((0, 2, 3)); isd = 1 / torch.sqrt(x.detach().var((0, 2, 3), unbiased=False) + 1e-5)
+    nb, part = _partials(m, c)
+    code = DTYPE_CODE[dtype]
+    lib.mi355_bn_bwd_reduce(dyd, c, yd, c, xd, c, dev(mu), dev(isd), part, m, c, act, code)
+    sums = torch.empty(2 * c, device=DEV); dgam = torch.ones(c, device=DEV); dbet = torch.ones(c, device=DEV)
+    lib.mi355_bn_bwd_finalize(part, nb, c, sums, dgam, dbet, 1.0)      # accumulate onto ones
+    dx = torch.empty_like(xd); dres = torch.empty_like(xd)
+    nb1, p1 = _partials(m, c, 1)
+    lib.mi355_bn_bwd_apply(dyd, c, yd, c, xd, c, dev(gamma.detach()), dev(mu), dev(isd), sums, dx, c,
+                           dres if with_res else None, c, p1, m, c, act, code)
+    dbias = torch.empty(c, device=DEV)
+    lib.mi355_colsum_finalize(p1, nb1, 1, c, dbias, 0.0)
+    torch.cuda.synchronize()
+    tol = 5e-5 if dtype == torch.float32 else 2e-2
+    assert rel_err(from_nhwc(dx), x.grad) < tol
+    assert rel_err(dgam.cpu() - 1, gamma.grad) < tol and rel_err(dbet.cpu() - 1, beta.grad) < tol
+    if with_res:
+        assert rel_err(from_nhwc(dres), res.grad) < tol
+    assert float(dbias.abs().max()) < 1e-2 * float(x.grad.abs().sum((0, 2, 3)).max())   # ~0: dx is mean-free
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_bn_act_two_operands_and_eval_coeffs(dtype):
+    n, c, h, w = 2, 32, 6, 6
+    g = torch.Generator().manual_seed(2)
+    a = q(torch.randn(n, c, h, w, generator=g), dtype); b = q(torch.randn(n, c, h, w, generator=g), dtype)
+    gam, bet, rm = (torch.randn(c, generator=g) for _ in range(3)); rv = torch.rand(c, generator=g) + 0.5
+    sc, sh = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    lib.mi355_bn_eval_coeffs(dev(gam), dev(bet), dev(rm), dev(rv), 1e-5, c, sc, sh)
+    s2, t2 = torch.randn(c, generator=g), torch.randn(c, generator=g)
+    ref = F.relu(F.batch_norm(a, rm, rv, gam, bet, False, 0.1, 1e-5) + b * s2[None, :, None, None] + t2[None, :, None, None])
+    y = torch.empty(n, h, w, 2 * c, dtype=dtype, device=DEV)          # write into a channel slice
+    lib.mi355_bn_act(to_nhwc(a, dtype), c, sc, sh, to_nhwc(b, dtype), c, dev(s2), dev(t2), None, 0,
+                     y.data_ptr() + c * y.element_size(), 2 * c, n * h * w, c, 1, DTYPE_CODE[dtype])
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(y[..., c:]), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("k,s,p,hw", [(2, 2, 0, 12), (3, 2, 1, 13), (3, 2, 1, 16)])
+def test_maxpool(dtype, k, s, p, hw):
+    n, c = 2, 32
+    g = torch.Generator().manual_seed(k * 10 + hw)
+    # coarse grid of values => many exact ties, exercising torch's first-max rule
+    x = (torch.randint(-3, 4, (n, c, hw, hw), generator=g).float() / 2).requires_grad_(True)
+    y = F.max_pool2d(x, k, s, p)
+    dy = q(torch.randn(y.shape, generator=g), dtype)
+    y.backward(dy)
+    code = DTYPE_CODE[dtype]
+    xd = to_nhwc(x.detach(), dtype)
+    yd = torch.empty(n, y.shape[2], y.shape[3], c, dtype=dtype, device=DEV)
+    lib.mi355_maxpool_fwd(xd, c, yd, c, n, hw, hw, c, k, s, p, code)
+    dx = torch.full_like(xd, 1.0)
+    lib.mi355_maxpool_bwd(xd, c, to_nhwc(dy, dtype), c, dx, c, n, hw, hw, c, k, s, p, 1, code)   # accumulate onto 1
+    torch.cuda.synchronize()
+    assert torch.equal(from_nhwc(yd), y.detach())
+    assert rel_err(from_nhwc(dx) - 1, x.grad) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_upsample_bwd_add_relu(dtype):
+    n, c, h, w = 2, 32, 5, 7
+    g = torch.Generator().manual_seed(9)
+    code = DTYPE_CODE[dtype]
+    x = torch.randn(n, c, h, w, generator=g, requires_grad=True)
+    dy = q(torch.randn(n, c, 2 * h, 2 * w, generator=g), dtype)
+    F.interpolate(x, scale_factor=2.0, mode="nearest").backward(dy)
+    dx = torch.empty(n, h, w, c, dtype=dtype, device=DEV)
+    lib.mi355_upsample2_bwd(to_nhwc(dy, dtype), c, dx, c, n, h, w, c, 0, code)
+    a, b = q(torch.randn(n, c, h, w, generator=g), dtype), q(torch.randn(n, c, h, w, generator=g), dtype)
+    ad, bd = to_nhwc(a, dtype), to_nhwc(b, dtype)
+    s_ = torch.empty_like(ad); r_ = torch.empty_like(ad); rb = torch.empty_like(ad)
+    lib.mi355_add(ad, c, bd, c, s_, c, n * h * w, c, code)
+    lib.mi355_relu_fwd(ad, c, r_, c, n * h * w, c, code)
+    lib.mi355_relu_bwd(bd, c, r_, c, rb, c, n * h * w, c, code)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(dx), x.grad) < TOL[dtype]
+    assert rel_err(from_nhwc(s_), a + b) < TOL[dtype]
+    assert torch.equal(from_nhwc(r_), F.relu(a)) and torch.equal(from_nhwc(rb), b * (a > 0))
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_pack_unpack_and_weight_pack(dtype):
+    code = DTYPE_CODE[dtype]
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 3, 9, 11, generator=g)
+    y = torch.full((2, 9, 11, 32), float("nan"), dtype=dtype, device=DEV)
+    lib.mi355_pack_input_nchw(dev(x), y, 2, 3, 9, 11, 32, code)
+    torch.cuda.synchronize()
+    assert torch.equal(y.float().cpu()[..., :3].permute(0, 3, 1, 2), q(x, dtype)) and float(y[..., 3:].abs().max()) == 0
+    x2 = torch.randn(2, 16, 5, 6, generator=g)
+    y2 = torch.zeros(2, 5, 6, 24, dtype=dtype, device=DEV)
+    lib.mi355_pack_nchw(dev(x2), y2, 2, 16, 5, 6, 24, code)
+    back = torch.empty(2, 16, 5, 6, device=DEV)
+    lib.mi355_unpack_output_nchw(y2, back, 2, 16, 5, 6, 24, code)
+    torch.cuda.synchronize()
+    assert torch.equal(back.cpu(), q(x2, dtype))
+    for transposed in (0, 1):
+        w = torch.randn(40, 3, 3, 3, generator=g) if not transposed else torch.randn(3, 40, 2, 2, generator=g)
+        co, ci = (40, 3)
+        kk = w.shape[2]
+        wf_ref, wb_ref = pack_w(w, dtype, cip=32, transposed=bool(transposed))
+        wf = torch.empty_like(wf_ref); wb = torch.empty_like(wb_ref)
+        lib.mi355_pack_conv_weight(dev(w), wf, wb, co, ci, 32, kk, kk, transposed, code)
+        torch.cuda.synchronize()
+        assert torch.equal(wf, wf_ref) and torch.equal(wb, wb_ref)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("c", [32, 64, 256])
+def test_attention_gate_tail(dtype, c):
+    """p -> z = psi-conv(p) -> BN(1) -> sigmoid -> x*psi, forward and full backward vs autograd."""
+    n, h, w, f = 2, 6, 5, 2 * c
+    code = DTYPE_CODE[dtype]
+    g = torch.Generator().manual_seed(c)
+    p = q(F.relu(torch.randn(n, c, h, w, generator=g)), dtype).requires_grad_(True)
+    x = q(torch.randn(n, f, h, w, generator=g), dtype).requires_grad_(True)
+    wp = (torch.randn(1, c, 1, 1, generator=g) / math.sqrt(c)).requires_grad_(True)
+    bp = torch.randn(1, generator=g).requires_grad_(True)
+    gam = torch.tensor([1.3], requires_grad=True); bet = torch.tensor([-0.2], requires_grad=True)
+    z = F.conv2d(p, wp, bp)
+    psi = torch.sigmoid(F.batch_norm(z, None, None, gam, bet, True, 0.1, 1e-5))
+    out = x * psi
+    dout = q(torch.randn(out.shape, generator=g), dtype)
+    out.backward(dout)
+    m = n * h * w
+    pd, xd = to_nhwc(p.detach(), dtype), to_nhwc(x.detach(), dtype)
+    zd = torch.empty(m, device=DEV)
+    nb, part = _partials(m, 1)
+    lib.mi355_rowdot_fwd(pd, c, dev(wp.detach().flatten()), dev(bp.detach()), zd, part, m, c, code)
+    sc, sh, mu, isd = (torch.empty(1, device=DEV) for _ in range(4))
+    lib.mi355_bn_finalize(part, nb, m, 1, dev(gam.detach()), dev(bet.detach()), None, None, None, 0.1, 1e-5, sc, sh, mu, isd)
+    od = torch.empty_like(xd)
+    lib.mi355_gate_mul_fwd(xd, f, zd, sc, sh, od, f, m, f, code)
+    # backward
+    dxd = torch.empty_like(xd); dzn = torch.empty(m, device=DEV)
+    nb2, part2 = _partials(m, 1)
+    lib.mi355_gate_mul_bwd(to_nhwc(dout, dtype), f, xd, f, zd, sc, sh, mu, isd, dxd, f, 0, dzn, part2, m, f, code)
+    sums = torch.empty(2, device=DEV); dgam = torch.zeros(1, device=DEV); dbet = torch.zeros(1, device=DEV)
+    lib.mi355_bn_bwd_finalize(part2, nb2, 1, sums, dgam, dbet, 0.0)
+    dz = torch.empty(m, device=DEV)
+    lib.mi355_bn1_bwd_apply(dzn, zd, dev(gam.detach()), mu, isd, sums, dz, m)
+    dpd = torch.empty_like(pd)
+    nb3, part3 = _partials(m, c)
+    lib.mi355_rowdot_bwd(dz, pd, c, dev(wp.detach().flatten()), dpd, c, part3, m, c, 0, code)
+    dw = torch.empty(c, device=DEV); db = torch.empty(c, device=DEV)
+    lib.mi355_colsum_finalize(part3, nb3, 2, c, dw, 0.0)
+    lib.mi355_colsum_finalize(part3[c:], nb3, 2, c, db, 0.0)
+    torch.cuda.synchronize()
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    assert rel_err(from_nhwc(od), out.detach()) < TOL[dtype]
+    assert rel_err(from_nhwc(dxd), x.grad) < tol
+    assert rel_err(dgam.cpu(), gam.grad) < tol and rel_err(dbet.cpu(), bet.grad) < tol
+    assert rel_err(from_nhwc(dpd), p.grad) < tol
+    assert rel_err(dw.cpu(), wp.grad.flatten()) < tol
+    assert abs(float(db[0]) - float(bp.grad)) < 1e-3 * float(wp.grad.abs().max()) + 1e-5   # ~0 (BN follows)
+
+
+def test_heads_and_losses():
+    g = torch.Generator().manual_seed(8)
+    n, c, hw = 3, 96, 20
+    for dtype in DT:
+        x = q(torch.randn(n, c, 4, 5, generator=g), dtype)
+        xd = to_nhwc(x, dtype)
+        for is_max in (1, 0):
+            y = torch.empty(n, c, device=DEV); am = torch.empty(n, c, dtype=torch.int32, device=DEV)
+            lib.mi355_global_pool_fwd(xd, c, y, am, n, hw, c, is_max, DTYPE_CODE[dtype])
+            xr = x.clone().requires_grad_(True)
+            ref = (F.adaptive_max_pool2d(xr, 1) if is_max else F.adaptive_avg_pool2d(xr, 1)).flatten(1)
+            dy = torch.randn(n, c, generator=g); ref.backward(dy)
+            dx = torch.empty_like(xd)
+            lib.mi355_global_pool_bwd(dev(dy), am, dx, c, n, hw, c, is_max, DTYPE_CODE[dtype])
+            torch.cuda.synchronize()
+            assert rel_err(y.cpu(), ref.detach()) < 1e-6 and rel_err(from_nhwc(dx), xr.grad) < TOL[dtype]
+    # linear fwd/bwd (+relu)
+    b, i, o = 4, 200, 7
+    x = torch.randn(b, i, generator=g, requires_grad=True); w = torch.randn(o, i, generator=g, requires_grad=True)
+    bias = torch.randn(o, generator=g, requires_grad=True)
+    y = F.relu(F.linear(x, w, bias)); dy = torch.randn(b, o, generator=g); y.backward(dy)
+    yd = torch.empty(b, o, device=DEV)
+    lib.mi355_linear_fwd(dev(x.detach()), dev(w.detach()), dev(bias.detach()), yd, b, i, o, 1)
+    dx, dw, db = torch.empty(b, i, device=DEV), torch.zeros(o, i, device=DEV), torch.zeros(o, device=DEV)
+    lib.mi355_linear_bwd(dev(x.detach()), dev(w.detach()), yd, dev(dy), dx, dw, db, b, i, o, 1, 0.0)
+    torch.cuda.synchronize()
+    assert rel_err(yd.cpu(), y.detach()) < 1e-5 and rel_err(dx.cpu(), x.grad) < 1e-5
+    assert rel_err(dw.cpu(), w.grad) < 1e-5 and rel_err(db.cpu(), bias.grad) < 1e-5
+    # dropout: keep-rate and scaling
+    nn_ = 1 << 18
+    xx = torch.ones(nn_, device=DEV); yy = torch.empty(nn_, device=DEV); mk = torch.empty(nn_, dtype=torch.uint8, device=DEV)
+    lib.mi355_dropout_fwd(xx, yy, mk, nn_, 0.3, 1234)
+    dd = torch.empty(nn_, device=DEV)
+    lib.mi355_dropout_bwd(xx, mk, dd, nn_, 0.3)
+    torch.cuda.synchronize()
+    keep = float(mk.float().mean())
+    assert abs(keep - 0.7) < 5e-3 and torch.equal(yy, dd) and abs(float(yy.max()) - 1 / 0.7) < 1e-6
+    # losses
+    z = torch.randn(4, 1, 16, 16, generator=g) * 3; t = (torch.rand(4, 1, 16, 16, generator=g) > 0.5).float()
+    zr = z.clone().requires_grad_(True); l = F.binary_cross_entropy_with_logits(zr, t); l.backward()
+    loss = torch.empty(1, device=DEV); dz = torch.empty(z.numel(), device=DEV)
+    lib.mi355_bce_logits(dev(z), dev(t), loss, dz, None, z.numel())
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(l)) < 1e-5 and rel_err(dz.cpu().view_as(z), zr.grad) < 1e-5
+    lg = torch.randn(6, 3, generator=g); yy_ = torch.randint(0, 3, (6,), generator=g)
+    lr_ = lg.clone().requires_grad_(True); l2 = F.cross_entropy(lr_, yy_, label_smoothing=0.1); l2.backward()
+    dl = torch.empty(6, 3, device=DEV)
+    lib.mi355_ce_smooth(dev(lg), dev(yy_), loss, dl, None, 6, 3, 0.1)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(l2)) < 1e-5 and rel_err(dl.cpu(), lr_.grad) < 1e-5
+
+
+def test_clip_and_adamw_match_torch():
+    g = torch.Generator().manual_seed(21)
+    n = 100_003
+    p0 = torch.randn(n, generator=g); p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([p], lr=1e-3, weight_decay=5e-4)
+    pd = dev(p0.clone()); pad = (-n) % 4
+    m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV)
+    lr = torch.tensor([1e-3], device=DEV); step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    norm, coef, finf = (torch.empty(1, device=DEV) for _ in range(3))
+    nb = lib.mi355_rowreduce_blocks(n); part = torch.empty(nb, device=DEV)
+    for it in range(3):
+        gr = torch.randn(n, generator=g) * (10 if it == 0 else 0.001)
+        p.grad = gr.clone()
+        tn = torch.nn.utils.clip_grad_norm_([p], 1.0)
+        opt.step()
+        gd = dev(gr)
+        lib.mi355_sumsq_partial(gd, part, n)
+        lib.mi355_clip_coef(part, nb, 1.0, 1.0, norm, coef, finf, step)
+        lib.mi355_adamw(pd, gd, m, v, n, lr, 0.9, 0.999, 1e-8, 5e-4, coef, 1.0, finf, step)
+        torch.cuda.synchronize()
+        assert abs(float(norm) - float(tn)) < 1e-4 * float(tn)
+        assert rel_err(pd.cpu(), p.detach()) < 1e-6
+    assert int(step) == 3
+    # non-finite gradient => step skipped, counter unchanged
+    gd = dev(torch.full((n,), float("inf")))
+    before = pd.clone()
+    lib.mi355_sumsq_partial(gd, part, n)
+    lib.mi355_clip_coef(part, nb, 1.0, 1.0, norm, coef, finf, step)
+    lib.mi355_adamw(pd, gd, m, v, n, lr, 0.9, 0.999, 1e-8, 5e-4, coef, 1.0, finf, step)
+    torch.cuda.synchronize()
+    assert torch.equal(pd, before) and int(step) == 3 and float(finf) == 1.0
+
+
+def test_seg_counts():
+    g = torch.Generator().manual_seed(2)
+    logit = torch.randn(3, 1, 33, 17, generator=g); t = (torch.rand(3, 1, 33, 17, generator=g) > 0.6).float()
+    cnt = torch.empty(3, 4, device=DEV)
+    lib.mi355_seg_counts(dev(logit), dev(t), cnt, 3, 33 * 17, 1, 0.5)
+    torch.cuda.synchronize()
+    pb = torch.sigmoid(logit) > 0.5; tb = t > 0.5
+    exp = torch.stack([(pb & tb).flatten(1).sum(1), pb.flatten(1).sum(1), tb.flatten(1).sum(1),
+                       (pb == tb).flatten(1).sum(1)], 1).float()
+    assert torch.equal(cnt.cpu(), exp)

@@ -178,9 +178,10 @@ int mi355_linear_fwd(const float* x, const float* w, const float* bias, float* y
                      mi355_stream_t s);
 int mi355_linear_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw,
                      float* db, int B, int I, int O, int relu, float beta, mi355_stream_t s);
-/* inverted dropout with a Philox-style counter hash: mask bit kept for backward. */
+/* inverted dropout with a counter hash (seed, counter[0], element index): mask byte kept for backward;
+ * `counter` is a device word the host bumps per forward so a static launch plan draws fresh masks. */
 int mi355_dropout_fwd(const float* x, float* y, uint8_t* mask, long long n, float p, uint64_t seed,
-                      mi355_stream_t s);
+                      const int32_t* counter, mi355_stream_t s);
 int mi355_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, long long n, float p, mi355_stream_t s);
 
 /* ---- losses (utils/helpers.py:244-246) ---------------------------------------------------- */

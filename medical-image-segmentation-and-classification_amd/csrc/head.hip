@@ -161,8 +161,9 @@ __device__ __forceinline__ uint32_t mix32(uint64_t k) {   // splitmix64 finalise
 }
 
 __global__ void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ mask, long long n,
-                                   float p, uint64_t seed) {
+                                   float p, uint64_t seed, const int32_t* __restrict__ counter) {
   const float scale = p < 1.f ? 1.f / (1.f - p) : 0.f;
+  if (counter) seed ^= (uint64_t)(uint32_t)counter[0] * 0xD1342543DE82EF95ull;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const float u = (float)(mix32(seed * 0x100000001B3ull + (uint64_t)i) >> 8) * (1.0f / 16777216.0f);
     const uint8_t keep = u >= p;
@@ -179,9 +180,9 @@ __global__ void dropout_bwd_kernel(const float* __restrict__ dy, const uint8_t* 
 }
 
 extern "C" int mi355_dropout_fwd(const float* x, float* y, uint8_t* mask, long long n, float p, uint64_t seed,
-                                 mi355_stream_t s) {
+                                 const int32_t* counter, mi355_stream_t s) {
   MI355_CHECK_ARG(x && y && mask && p >= 0.f && p <= 1.f, "dropout_fwd: bad arguments");
-  hipLaunchKernelGGL(dropout_fwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)s, x, y, mask, n, p, seed);
+  hipLaunchKernelGGL(dropout_fwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)s, x, y, mask, n, p, seed, counter);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }

@@ -1,0 +1,856 @@
+"""Static launch plans for the MI355X conv-net path.
+
+A model's forward is described ONCE per (input shape, mode) as a sequence of C-ABI launches
+over preallocated HBM buffers (`Builder`); the matching backward sequence is generated at the
+same time by reverse-mode rules attached to each op.  Executing a step is then a flat loop of
+ctypes calls on one HIP stream — no tracing, no per-op autograd nodes, no allocation, and the
+whole loop is hipGraph-capturable.
+
+Data layout in HBM: activations are NHWC rows of the compute dtype (bf16 or
+fp32); a concatenation is one wide buffer whose producers write their channel slice directly
+(`new_cat`), so torch.cat (AttentionUNet.py:101,106,111,116) costs nothing; statistics,
+parameters, packed-weight masters and parameter gradients are fp32.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from .lib import lib, DTYPE_CODE
+
+BN_EPS_DEFAULT = 1e-5
+CPAD = 32          # network inputs are zero-padded to 32 channels (MFMA K granularity)
+
+
+class T:
+    """NHWC activation handle: rows of C channels with channel stride ld inside `buf`."""
+    __slots__ = ("buf", "off", "N", "H", "W", "C", "ld", "_ng", "_grad", "parent", "_written", "name")
+
+    def __init__(self, buf, off, N, H, W, C, ld, parent=None):
+        self.buf, self.off = buf, off
+        self.N, self.H, self.W, self.C, self.ld = N, H, W, C, ld
+        self._ng = False
+        self._grad = None
+        self.parent = parent
+        self._written = False
+        self.name = ""
+
+    @property
+    def needs_grad(self):
+        return self._ng
+
+    @needs_grad.setter
+    def needs_grad(self, v):
+        self._ng = bool(v)
+        if v and self.parent is not None:       # a concat needs a gradient as soon as one slice does
+            self.parent._ng = True
+
+    @property
+    def M(self):
+        return self.N * self.H * self.W
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr() + self.off * self.buf.element_size()
+
+    def torch_view(self):
+        """[N,H,W,C] strided torch view (tests / debugging only)."""
+        flat = self.buf[self.off:]
+        return flat.as_strided((self.N, self.H, self.W, self.C), (self.H * self.W * self.ld, self.W * self.ld, self.ld, 1))
+
+
+class V:
+    """Small fp32 matrix [B, F] (classifier heads)."""
+    __slots__ = ("buf", "B", "F", "needs_grad", "_grad", "_written")
+
+    def __init__(self, buf, B, F):
+        self.buf, self.B, self.F = buf, B, F
+        self.needs_grad = False
+        self._grad = None
+        self._written = False
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr()
+
+
+class GRef:
+    """Location of a parameter's gradient inside the engine's flat fp32 gradient buffer."""
+    __slots__ = ("tensor", "off", "param")
+
+    def __init__(self, tensor, off, param):
+        self.tensor, self.off, self.param = tensor, off, param
+
+
+class Ws:
+    """Late-bound shared workspace pointer (sized to the largest request of the plan)."""
+    __slots__ = ("kind",)
+
+    def __init__(self, kind):
+        self.kind = kind
+
+
+class Launch:
+    __slots__ = ("name", "args")
+
+    def __init__(self, name, *args):
+        self.name, self.args = name, args
+
+
+class Plan:
+    """Executable product of a Builder."""
+
+    def __init__(self, b: "Builder"):
+        self.device = b.device
+        self.dtype = b.dtype
+        self.training = b.training
+        self.pre, self.fwd, self.bwd = b.pre, b.fwd, b.bwd
+        self.keep = b.keep
+        self.input = b.input
+        self.output = b.output            # ("z", tensor[M], N,H,W) or ("v", V)
+        self.dout = b.dout                # fp32 buffer the loss writes dL/dlogits into
+        self.input_grad = getattr(b, "input_grad", None)   # NCHW fp32 dL/dx when requested
+        self.ws = {k: (torch.empty(max(n, 16), dtype=torch.uint8 if k == "bytes" else torch.float32, device=b.device))
+                   for k, n in b.ws_need.items()}
+        self.param_ptrs = [(p, p.data_ptr()) for p in b.params_seen]
+        self.grad_params = list(b.grad_params)   # parameters that receive a gradient, in write order
+        self._bound = {}
+        self.n_launches = (len(self.pre) + len(self.fwd), len(self.bwd))
+        # index of the last backward launch that writes each parameter's gradient (data-parallel
+        # buckets become ready right after it)
+        self.last_write = {}
+        for i, l in enumerate(self.bwd):
+            for a in l.args:
+                if isinstance(a, GRef):
+                    self.last_write[id(a.param)] = i
+
+    # -- binding: resolve pointers once per stream --------------------------------------------
+    def _resolve(self, launches: List[Launch], stream):
+        out = []
+        for l in launches:
+            fn = lib.raw(l.name)
+            conv = []
+            for a in l.args:
+                if isinstance(a, (T, V)):
+                    conv.append(a.ptr)
+                elif isinstance(a, torch.Tensor):
+                    conv.append(a.data_ptr())
+                elif isinstance(a, Ws):
+                    conv.append(self.ws[a.kind].data_ptr())
+                elif isinstance(a, GRef):
+                    conv.append(a.tensor.data_ptr() + a.off)
+                elif isinstance(a, tuple):          # (tensor, byte offset)
+                    conv.append(a[0].data_ptr() + a[1])
+                else:
+                    conv.append(a)
+            conv.append(stream)
+            if len(conv) != len(fn.argtypes):
+                raise TypeError(f"{l.name}: built {len(conv)} args, ABI takes {len(fn.argtypes)}")
+            out.append((fn, tuple(conv), l.name))
+        return out
+
+    def bind(self, stream):
+        key = int(stream or 0)
+        if key not in self._bound:
+            self._bound[key] = (self._resolve(self.pre + self.fwd, stream), self._resolve(self.bwd, stream))
+        return self._bound[key]
+
+    @staticmethod
+    def _run(calls):
+        for fn, args, name in calls:
+            rc = fn(*args)
+            if rc:
+                raise RuntimeError(f"{name} failed (rc={rc}): {lib.raw('mi355_last_error')().decode()}")
+
+    def run_forward(self, stream):
+        self._run(self.bind(stream)[0])
+
+    def run_backward(self, stream):
+        self._run(self.bind(stream)[1])
+
+    def params_moved(self):
+        return any(p.data_ptr() != ptr for p, ptr in self.param_ptrs)
+
+
+class Builder:
+    """Emits forward launches and registers reverse-mode rules; `finish()` returns a Plan."""
+
+    def __init__(self, engine, device, dtype, training, want_grad):
+        self.engine = engine
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.code = DTYPE_CODE[dtype]
+        self.esz = 2 if dtype == torch.bfloat16 else 4
+        self.epc = 16 // self.esz
+        self.training = training
+        self.want_grad = want_grad and training
+        self.pre: List[Launch] = []
+        self.fwd: List[Launch] = []
+        self.bwd: List[Launch] = []
+        self._rules = []                 # closures, run in reverse at finish()
+        self.keep = []
+        self.ws_need = {"bytes": 0, "f32": 0}
+        self._packs = {}
+        self._grad_first = {}
+        self.params_seen = []
+        self.grad_params = []
+        self.input = None
+        self.output = None
+        self.dout = None
+        self.bn_momentum = 0.1
+
+    # ---- allocation ---------------------------------------------------------------------------
+    def _alloc(self, numel, dtype=None):
+        t = torch.empty(max(int(numel), 8), dtype=dtype or self.dtype, device=self.device)
+        self.keep.append(t)
+        return t
+
+    def f32(self, n, fill=None):
+        t = self._alloc(n, torch.float32)
+        if fill is not None:
+            t.fill_(fill)
+        return t
+
+    def new_tensor(self, N, H, W, C):
+        return T(self._alloc(N * H * W * C), 0, N, H, W, C, C)
+
+    def new_cat(self, N, H, W, parts):
+        """One wide buffer + channel-slice views (slice i covers parts[i] channels)."""
+        tot = sum(parts)
+        full = self.new_tensor(N, H, W, tot)
+        slices, o = [], 0
+        for c in parts:
+            slices.append(T(full.buf, o, N, H, W, c, tot, parent=full))
+            o += c
+        return full, slices
+
+    def ws_bytes(self, n):
+        self.ws_need["bytes"] = max(self.ws_need["bytes"], int(n))
+        return Ws("bytes")
+
+    def ws_f32(self, n):
+        self.ws_need["f32"] = max(self.ws_need["f32"], int(n))
+        return Ws("f32")
+
+    # ---- gradient bookkeeping ---------------------------------------------------------------------
+    def grad_of(self, t):
+        """Gradient handle of an activation (allocated on first use; slices share the parent's)."""
+        if t._grad is None:
+            if isinstance(t, V):
+                t._grad = V(self.f32(t.B * t.F), t.B, t.F)
+            elif t.parent is not None:
+                pg = self.grad_of(t.parent)
+                t._grad = T(pg.buf, t.off, t.N, t.H, t.W, t.C, pg.ld, parent=pg)
+            else:
+                t._grad = T(self._alloc(t.M * t.ld), 0, t.N, t.H, t.W, t.C, t.ld)
+        return t._grad
+
+    def acc_flag(self, t):
+        """0 for the first gradient contribution to `t` in backward order, 1 afterwards."""
+        g = self.grad_of(t)
+        root = g.parent if (not isinstance(g, V) and g.parent is not None) else g
+        was = g._written or root._written
+        g._written = True
+        if root is not g and g.C == root.C:
+            root._written = True
+        return 1 if was else 0
+
+    def mark_full_written(self, t):
+        g = self.grad_of(t)
+        g._written = True
+
+    def pgrad(self, p):
+        """(flat grad tensor, byte offset) of parameter p and the beta (0 first write, 1 after)."""
+        ref = self.engine.grad_ref(p)
+        first = id(p) not in self._grad_first
+        self._grad_first[id(p)] = True
+        if first:
+            self.grad_params.append(p)
+        return ref, (0.0 if first else 1.0)
+
+    def see(self, *params):
+        for p in params:
+            if p is not None:
+                self.params_seen.append(p)
+
+    def rule(self, fn):
+        if self.want_grad:
+            self._rules.append(fn)
+
+    # ---- input / output ----------------------------------------------------------------------------
+    def set_input(self, x_shape):
+        N, C, H, W = x_shape
+        self.input = (self.f32(N * C * H * W), (N, C, H, W))
+        cpad = (C + CPAD - 1) // CPAD * CPAD
+        xin = self.new_tensor(N, H, W, cpad)
+        self.pre.append(Launch("mi355_pack_input_nchw", self.input[0], xin, N, C, H, W, cpad, self.code))
+        self.input_grad = None
+        return xin
+
+    def want_input_grad(self, xin):
+        """Make the packed network input differentiable (block-level tests / composed pipelines): after
+        backward, `plan.input_grad` holds dL/dx as NCHW fp32."""
+        xin.needs_grad = True
+        N, C, H, W = self.input[1]
+        self.input_grad = self.f32(N * C * H * W)
+
+        def rule():
+            g = self.grad_of(xin)
+            self.bwd.append(Launch("mi355_unpack_output_nchw", g, self.input_grad, N, C, H, W, g.ld, self.code))
+        if self.want_grad:
+            self._rules.insert(0, rule)      # runs last in backward order
+
+    def slice_channels(self, t, c0, c):
+        """View of channels [c0, c0+c) of an activation (shares storage and gradient)."""
+        root = t.parent if t.parent is not None else t
+        s = T(t.buf, t.off + c0, t.N, t.H, t.W, c, t.ld, parent=root)
+        s._ng = t.needs_grad
+        return s
+
+    def tensor_output(self, t):
+        """Expose an activation as the model output: NCHW fp32 (multi-channel heads, block tests)."""
+        N, C, H, W = t.N, t.C, t.H, t.W
+        out = self.f32(N * C * H * W)
+        self.fwd.append(Launch("mi355_unpack_output_nchw", t, out, N, C, H, W, t.ld, self.code))
+        self.output = ("z", out, (N, C, H, W))
+        if self.want_grad and t.needs_grad:
+            self.dout = self.f32(N * C * H * W)
+
+            def rule():
+                if self.acc_flag(t):
+                    raise NotImplementedError("tensor_output of an activation with other consumers")
+                g = self.grad_of(t)
+                self.bwd.append(Launch("mi355_pack_nchw", self.dout, g, N, C, H, W, g.ld, self.code))
+            self.rule(rule)
+        return out
+
+    # ---- packed weights -------------------------------------------------------------------------------
+    def packs(self, conv, cip, transposed=False):
+        key = (id(conv), cip)
+        if key not in self._packs:
+            w = conv.weight
+            if transposed:
+                ci, co = w.shape[0], w.shape[1]
+            else:
+                co, ci = w.shape[0], w.shape[1]
+            k = w.shape[2]
+            wf = self._alloc(co * k * k * cip)
+            wb = self._alloc(co * k * k * cip) if self.want_grad else None
+            self.pre.append(Launch("mi355_pack_conv_weight", w, wf, wb, co, ci, cip, k, k, 1 if transposed else 0, self.code))
+            self.see(w, conv.bias)
+            self._packs[key] = (wf, wb)
+        return self._packs[key]
+
+    # ---- convolution -----------------------------------------------------------------------------------
+    def _conv_geom(self, x, conv, up):
+        k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        if conv.kernel_size[0] != conv.kernel_size[1] or conv.dilation[0] != 1 or conv.groups != 1:
+            raise NotImplementedError("square, undilated, ungrouped convolutions only")
+        hl, wl = (2 * x.H, 2 * x.W) if up else (x.H, x.W)
+        return k, s, p, (hl + 2 * p - k) // s + 1, (wl + 2 * p - k) // s + 1
+
+    def conv_raw(self, x, conv, up=False, out=None):
+        """y = conv(x) (+bias), raw output in the compute dtype; returns (y, bwd(dy, bias_done))."""
+        k, s, p, Ho, Wo = self._conv_geom(x, conv, up)
+        Co = conv.out_channels
+        assert x.C >= conv.in_channels and (x.C == conv.in_channels or conv.in_channels < CPAD), (x.C, conv.in_channels)
+        wf, wb = self.packs(conv, x.C)
+        y = out if out is not None else self.new_tensor(x.N, Ho, Wo, Co)
+        assert (y.N, y.H, y.W, y.C) == (x.N, Ho, Wo, Co)
+        self.fwd.append(Launch("mi355_conv2d_igemm", x, wf, conv.bias, y, x.N, x.H, x.W, x.C, x.ld, Ho, Wo, Co, y.ld,
+                               k, k, s, 1, -p, 1, 1 if up else 0, 0, self.code))
+        y.needs_grad = x.needs_grad or conv.weight.requires_grad
+
+        def bwd(dy, bias_done=False):
+            if conv.weight.requires_grad:
+                splits = lib.mi355_conv2d_wgrad_splits(x.N, Ho, Wo, x.C, Co, k, k)
+                ws = self.ws_bytes(splits * Co * k * k * x.C * 4)
+                self.bwd.append(Launch("mi355_conv2d_wgrad", x, dy, ws, splits, x.N, x.H, x.W, x.C, x.ld, Ho, Wo, Co, dy.ld,
+                                       k, k, s, p, 1 if up else 0, self.code))
+                ref, beta = self.pgrad(conv.weight)
+                self.bwd.append(Launch("mi355_conv2d_wgrad_reduce", ws, splits, ref, Co, x.C, conv.in_channels, k, k, 0, beta))
+            if conv.bias is not None and conv.bias.requires_grad and not bias_done:
+                self.bias_grad_from(dy, conv.bias)
+            if x.needs_grad:
+                if up:
+                    tmp = self.new_tensor(x.N, 2 * x.H, 2 * x.W, x.C)
+                    self.bwd.append(Launch("mi355_conv2d_igemm", dy, wb, None, tmp, x.N, Ho, Wo, Co, dy.ld, 2 * x.H, 2 * x.W,
+                                           x.C, tmp.ld, k, k, 1, -1, p, s, 0, 0, self.code))
+                    acc = self.acc_flag(x)
+                    xg = self.grad_of(x)
+                    self.bwd.append(Launch("mi355_upsample2_bwd", tmp, tmp.ld, xg, xg.ld, x.N, x.H, x.W, x.C, acc, self.code))
+                else:
+                    acc = self.acc_flag(x)
+                    xg = self.grad_of(x)
+                    self.bwd.append(Launch("mi355_conv2d_igemm", dy, wb, None, xg, x.N, Ho, Wo, Co, dy.ld, x.H, x.W, x.C,
+                                           xg.ld, k, k, 1, -1, p, s, 0, acc, self.code))
+        return y, bwd
+
+    def bias_grad_from(self, dy, bias):
+        nb = lib.mi355_rowreduce_blocks(dy.M)
+        part = self.ws_f32(nb * dy.C)
+        self.bwd.append(Launch("mi355_colsum", dy, dy.ld, part, dy.M, dy.C, self.code))
+        ref, beta = self.pgrad(bias)
+        self.bwd.append(Launch("mi355_colsum_finalize", part, nb, 1, dy.C, ref, beta))
+
+    # ---- batch norm state ---------------------------------------------------------------------------------
+    def _bn_coeffs(self, y, bn):
+        """Emit statistics (train) or running-stat coefficients (eval); returns dict of fp32 buffers."""
+        C = bn.num_features
+        st = {k: self.f32(C) for k in ("scale", "shift", "mean", "invstd")}
+        self.see(bn.weight, bn.bias)
+        if self.training:
+            nb = lib.mi355_rowreduce_blocks(y.M)
+            part = self.ws_f32(nb * 2 * C)
+            self.fwd.append(Launch("mi355_bn_stats", y, part, y.M, C, y.ld, self.code))
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            track = bn.track_running_stats
+            self.fwd.append(Launch("mi355_bn_finalize", part, nb, y.M, C, bn.weight, bn.bias,
+                                   bn.running_mean if track else None, bn.running_var if track else None,
+                                   bn.num_batches_tracked if track else None, float(mom), float(bn.eps),
+                                   st["scale"], st["shift"], st["mean"], st["invstd"]))
+        else:
+            self.fwd.append(Launch("mi355_bn_eval_coeffs", bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps),
+                                   C, st["scale"], st["shift"]))
+        return st
+
+    def _bn_bwd(self, da, a, y, bn, st, act, dres_to=None, bias=None):
+        """Emit BN(+ReLU) backward: returns dy (grad of the raw input y)."""
+        C = bn.num_features
+        nb = lib.mi355_rowreduce_blocks(y.M)
+        part = self.ws_f32(nb * 2 * C)
+        self.bwd.append(Launch("mi355_bn_bwd_reduce", da, da.ld, a if act else None, a.ld if act else 0, y, y.ld,
+                               st["mean"], st["invstd"], part, y.M, C, 1 if act else 0, self.code))
+        sums = self.f32(2 * C)
+        need_pg = bn.weight.requires_grad
+        if need_pg:
+            gref, gbeta = self.pgrad(bn.weight)
+            bref, _ = self.pgrad(bn.bias)
+        self.bwd.append(Launch("mi355_bn_bwd_finalize", part, nb, C, sums, gref if need_pg else None,
+                               bref if need_pg else None, gbeta if need_pg else 0.0))
+        dy = self.grad_of(y)
+        dres = None
+        if dres_to is not None and dres_to.needs_grad:
+            if self.acc_flag(dres_to):
+                dres = self.new_tensor(y.N, y.H, y.W, C)      # accumulate through a temporary
+            else:
+                dres = self.grad_of(dres_to)
+        want_bias = bias is not None and bias.requires_grad
+        part1 = self.ws_f32(nb * 2 * C + nb * C) if want_bias else None
+        self.bwd.append(Launch("mi355_bn_bwd_apply", da, da.ld, a if act else None, a.ld if act else 0, y, y.ld, bn.weight,
+                               st["mean"], st["invstd"], sums, dy, dy.ld, dres, dres.ld if dres is not None else 0,
+                               (self._ws_off(part1, nb * 2 * C * 4) if want_bias else None), y.M, C, 1 if act else 0, self.code))
+        if want_bias:
+            ref, beta = self.pgrad(bias)
+            self.bwd.append(Launch("mi355_colsum_finalize", self._ws_off(part1, nb * 2 * C * 4), nb, 1, C, ref, beta))
+        if dres is not None and dres is not dres_to._grad:
+            rg = self.grad_of(dres_to)
+            self.bwd.append(Launch("mi355_add", rg, rg.ld, dres, dres.ld, rg, rg.ld, y.M, C, self.code))
+        return dy
+
+    class _WsOff:
+        __slots__ = ("ws", "off")
+
+        def __init__(self, ws, off):
+            self.ws, self.off = ws, off
+
+    def _ws_off(self, ws, off):
+        return Builder._WsOff(ws, off)
+
+    # ---- fused block ops -------------------------------------------------------------------------------------
+    def conv_bn_act(self, x, conv, bn, act=True, up=False, out=None, res=None):
+        """act(bn(conv(x)) [+ res]) — the workhorse (AttentionUNet.py:4-13,15-27; ResNet.py:36-44)."""
+        y, conv_bwd = self.conv_raw(x, conv, up)
+        st = self._bn_coeffs(y, bn)
+        a = out if out is not None else self.new_tensor(y.N, y.H, y.W, y.C)
+        self.fwd.append(Launch("mi355_bn_act", y, y.ld, st["scale"], st["shift"], None, 0, None, None,
+                               res, res.ld if res is not None else 0, a, a.ld, y.M, y.C, 1 if act else 0, self.code))
+        a.needs_grad = y.needs_grad or bn.weight.requires_grad or (res is not None and res.needs_grad)
+
+        def rule():
+            if not a.needs_grad:
+                return
+            da = self.grad_of(a)
+            dy = self._bn_bwd(da, a, y, bn, st, act, dres_to=res, bias=conv.bias)
+            conv_bwd(dy, bias_done=True)
+        self.rule(rule)
+        return a
+
+    def bn_act(self, x, bn, act=False, out=None):
+        """Stand-alone BatchNorm (+ReLU) on an activation (ResNet.py:134: bn1 applied a second time)."""
+        st = self._bn_coeffs(x, bn)
+        a = out if out is not None else self.new_tensor(x.N, x.H, x.W, x.C)
+        self.fwd.append(Launch("mi355_bn_act", x, x.ld, st["scale"], st["shift"], None, 0, None, None, None, 0, a, a.ld,
+                               x.M, x.C, 1 if act else 0, self.code))
+        a.needs_grad = x.needs_grad or bn.weight.requires_grad
+
+        def rule():
+            if not a.needs_grad:
+                return
+            da = self.grad_of(a)
+            if x.needs_grad and self.acc_flag(x):
+                raise NotImplementedError("bn_act input with several consumers")
+            self._bn_bwd(da, a, x, bn, st, act)
+        self.rule(rule)
+        return a
+
+    def conv_act(self, x, conv, relu=False, up=False, out=None):
+        """conv (+bias) with optional ReLU and no normalisation (VGG.py:9-41; R2AttU_Net.py:54)."""
+        y, conv_bwd = self.conv_raw(x, conv, up, out=None if relu else out)
+        if not relu:
+            def rule():
+                if y.needs_grad:
+                    conv_bwd(self.grad_of(y))
+            self.rule(rule)
+            return y
+        a = out if out is not None else self.new_tensor(y.N, y.H, y.W, y.C)
+        self.fwd.append(Launch("mi355_relu_fwd", y, y.ld, a, a.ld, y.M, y.C, self.code))
+        a.needs_grad = y.needs_grad
+
+        def rule():
+            if not a.needs_grad:
+                return
+            da, dy = self.grad_of(a), self.grad_of(y)
+            self.bwd.append(Launch("mi355_relu_bwd", da, da.ld, a, a.ld, dy, dy.ld, y.M, y.C, self.code))
+            conv_bwd(dy)
+        self.rule(rule)
+        return a
+
+    def conv_transpose(self, x, mod, out=None):
+        """ConvTranspose2d(k, stride=k) (ResnetUnet.py:21,51) as the data-gradient form of the igemm."""
+        k, s = mod.kernel_size[0], mod.stride[0]
+        assert k == s and mod.padding[0] == 0 and mod.output_padding[0] == 0
+        Ci, Co = mod.in_channels, mod.out_channels
+        assert x.C == Ci
+        wf, wb = self.packs(mod, Ci, transposed=True)
+        Ho, Wo = x.H * s, x.W * s
+        y = out if out is not None else self.new_tensor(x.N, Ho, Wo, Co)
+        self.fwd.append(Launch("mi355_conv2d_igemm", x, wf, mod.bias, y, x.N, x.H, x.W, Ci, x.ld, Ho, Wo, Co, y.ld, k, k,
+                               1, -1, 0, s, 0, 0, self.code))
+        y.needs_grad = x.needs_grad or mod.weight.requires_grad
+
+        def rule():
+            if not y.needs_grad:
+                return
+            dy = self.grad_of(y)
+            if mod.weight.requires_grad:
+                # roles swap: the big tensor dy is gathered with stride-s addressing, x is the "dy" operand
+                splits = lib.mi355_conv2d_wgrad_splits(x.N, x.H, x.W, Co, Ci, k, k)
+                ws = self.ws_bytes(splits * Ci * k * k * Co * 4)
+                self.bwd.append(Launch("mi355_conv2d_wgrad", dy, x, ws, splits, x.N, Ho, Wo, Co, dy.ld, x.H, x.W, Ci, x.ld,
+                                       k, k, s, 0, 0, self.code))
+                ref, beta = self.pgrad(mod.weight)
+                self.bwd.append(Launch("mi355_conv2d_wgrad_reduce", ws, splits, ref, Ci, Co, Co, k, k, 0, beta))
+                if mod.bias is not None:
+                    self.bias_grad_from(dy, mod.bias)
+            if x.needs_grad:
+                acc = self.acc_flag(x)
+                xg = self.grad_of(x)
+                self.bwd.append(Launch("mi355_conv2d_igemm", dy, wb, None, xg, x.N, Ho, Wo, Co, dy.ld, x.H, x.W, Ci, xg.ld,
+                                       k, k, s, 1, 0, 1, 0, acc, self.code))
+        self.rule(rule)
+        return y
+
+    # ---- pooling / add -----------------------------------------------------------------------------------------
+    def maxpool(self, x, k=2, s=2, p=0):
+        Ho, Wo = (x.H + 2 * p - k) // s + 1, (x.W + 2 * p - k) // s + 1
+        y = self.new_tensor(x.N, Ho, Wo, x.C)
+        self.fwd.append(Launch("mi355_maxpool_fwd", x, x.ld, y, y.ld, x.N, x.H, x.W, x.C, k, s, p, self.code))
+        y.needs_grad = x.needs_grad
+
+        def rule():
+            if not y.needs_grad:
+                return
+            dy = self.grad_of(y)
+            acc = self.acc_flag(x)
+            xg = self.grad_of(x)
+            self.bwd.append(Launch("mi355_maxpool_bwd", x, x.ld, dy, dy.ld, xg, xg.ld, x.N, x.H, x.W, x.C, k, s, p, acc, self.code))
+        self.rule(rule)
+        return y
+
+    def add(self, a, b, out=None):
+        y = out if out is not None else self.new_tensor(a.N, a.H, a.W, a.C)
+        self.fwd.append(Launch("mi355_add", a, a.ld, b, b.ld, y, y.ld, a.M, a.C, self.code))
+        y.needs_grad = a.needs_grad or b.needs_grad
+
+        def rule():
+            if not y.needs_grad:
+                return
+            dy = self.grad_of(y)
+            for t in (a, b):
+                if t.needs_grad:
+                    acc = self.acc_flag(t)
+                    g = self.grad_of(t)
+                    self.bwd.append(Launch("mi355_add", dy, dy.ld, g if acc else None, g.ld, g, g.ld, a.M, a.C, self.code))
+        self.rule(rule)
+        return y
+
+    def copy(self, a, out):
+        """out = a (a plain skip tensor placed into a concat slice, R2U_Net.py:89)."""
+        self.fwd.append(Launch("mi355_add", a, a.ld, None, 0, out, out.ld, a.M, a.C, self.code))
+        out.needs_grad = a.needs_grad
+
+        def rule():
+            if not a.needs_grad:
+                return
+            dy = self.grad_of(out)
+            acc = self.acc_flag(a)
+            ga = self.grad_of(a)
+            self.bwd.append(Launch("mi355_add", dy, dy.ld, ga if acc else None, ga.ld, ga, ga.ld, a.M, a.C, self.code))
+        self.rule(rule)
+        return out
+
+    def head(self, mod, x):
+        """Classifier head: a Linear or a Sequential ending in one (helpers.py:124-143 may have
+        inserted Dropout in front); the last Linear's fp32 output is the model output."""
+        mods = list(mod) if isinstance(mod, nn.Sequential) else [mod]
+        assert isinstance(mods[-1], nn.Linear), "classifier head must end in nn.Linear"
+        v = self.seq(mods[:-1], x) if len(mods) > 1 else x
+        return self.linear(v, mods[-1], relu=False, is_output=True)
+
+    # ---- attention gate (AttentionUNet.py:29-54) -------------------------------------------------------------------
+    def gate(self, att, g, x, out=None):
+        cg, bg = att.W_g[0], att.W_g[1]
+        cx, bx = att.W_x[0], att.W_x[1]
+        cp, bp = att.psi[0], att.psi[1]
+        F_int = cg.out_channels
+        M = x.M
+        g1, g1_bwd = self.conv_raw(g, cg)
+        sg = self._bn_coeffs(g1, bg)
+        x1, x1_bwd = self.conv_raw(x, cx)
+        sx = self._bn_coeffs(x1, bx)
+        p = self.new_tensor(x.N, x.H, x.W, F_int)
+        self.fwd.append(Launch("mi355_bn_act", g1, g1.ld, sg["scale"], sg["shift"], x1, x1.ld, sx["scale"], sx["shift"],
+                               None, 0, p, p.ld, M, F_int, 1, self.code))
+        z = self.f32(M)
+        nb = lib.mi355_rowreduce_blocks(M)
+        sp = {k: self.f32(1) for k in ("scale", "shift", "mean", "invstd")}
+        self.see(cp.weight, cp.bias, bp.weight, bp.bias)
+        if self.training:
+            part = self.ws_f32(nb * 2)
+            self.fwd.append(Launch("mi355_rowdot_fwd", p, p.ld, cp.weight, cp.bias, z, part, M, F_int, self.code))
+            track = bp.track_running_stats
+            self.fwd.append(Launch("mi355_bn_finalize", part, nb, M, 1, bp.weight, bp.bias,
+                                   bp.running_mean if track else None, bp.running_var if track else None,
+                                   bp.num_batches_tracked if track else None, float(bp.momentum or 0.1), float(bp.eps),
+                                   sp["scale"], sp["shift"], sp["mean"], sp["invstd"]))
+        else:
+            self.fwd.append(Launch("mi355_rowdot_fwd", p, p.ld, cp.weight, cp.bias, z, None, M, F_int, self.code))
+            self.fwd.append(Launch("mi355_bn_eval_coeffs", bp.weight, bp.bias, bp.running_mean, bp.running_var, float(bp.eps), 1,
+                                   sp["scale"], sp["shift"]))
+        y = out if out is not None else self.new_tensor(x.N, x.H, x.W, x.C)
+        self.fwd.append(Launch("mi355_gate_mul_fwd", x, x.ld, z, sp["scale"], sp["shift"], y, y.ld, M, x.C, self.code))
+        trainable = any(q.requires_grad for q in att.parameters())
+        y.needs_grad = x.needs_grad or g.needs_grad or trainable
+
+        def rule():
+            if not y.needs_grad:
+                return
+            dy = self.grad_of(y)
+            # x*psi : dx += dy*psi, dzn = (sum_c dy*x) psi (1-psi) and its BN(1) reductions
+            dzn = self.f32(M)
+            part2 = self.ws_f32(nb * 2)
+            if x.needs_grad:
+                acc = self.acc_flag(x)
+                xg = self.grad_of(x)
+            else:
+                acc, xg = 0, self.new_tensor(x.N, x.H, x.W, x.C)
+            self.bwd.append(Launch("mi355_gate_mul_bwd", dy, dy.ld, x, x.ld, z, sp["scale"], sp["shift"], sp["mean"], sp["invstd"],
+                                   xg, xg.ld, acc, dzn, part2, M, x.C, self.code))
+            sums = self.f32(2)
+            gref, gbeta = self.pgrad(bp.weight)
+            bref, _ = self.pgrad(bp.bias)
+            self.bwd.append(Launch("mi355_bn_bwd_finalize", part2, nb, 1, sums, gref, bref, gbeta))
+            dz = self.f32(M)
+            self.bwd.append(Launch("mi355_bn1_bwd_apply", dzn, z, bp.weight, sp["mean"], sp["invstd"], sums, dz, M))
+            # psi conv (F_int -> 1): dp = dz*w masked by p>0, dw, db
+            dp = self.new_tensor(x.N, x.H, x.W, F_int)
+            part3 = self.ws_f32(nb * 2 * F_int)
+            self.bwd.append(Launch("mi355_rowdot_bwd", dz, p, p.ld, cp.weight, dp, dp.ld, part3, M, F_int, 1, self.code))
+            wref, wbeta = self.pgrad(cp.weight)
+            self.bwd.append(Launch("mi355_colsum_finalize", part3, nb, 2, F_int, wref, wbeta))
+            bref2, bbeta = self.pgrad(cp.bias)
+            self.bwd.append(Launch("mi355_colsum_finalize", self._ws_off(part3, F_int * 4), nb, 2 * F_int, 1, bref2, bbeta))
+            # the two normalised branches share dp
+            dg1 = self._bn_bwd(dp, None, g1, bg, sg, False, bias=cg.bias)
+            g1_bwd(dg1, bias_done=True)
+            dx1 = self._bn_bwd(dp, None, x1, bx, sx, False, bias=cx.bias)
+            x1_bwd(dx1, bias_done=True)
+        self.rule(rule)
+        return y
+
+    # ---- single-output 1x1 conv producing the fp32 logit map (AttentionUNet.py:84,119) -------------------------------
+    def logit_conv(self, x, conv):
+        assert conv.out_channels == 1 and conv.kernel_size[0] == 1
+        M = x.M
+        z = self.f32(M)
+        self.see(conv.weight, conv.bias)
+        self.fwd.append(Launch("mi355_rowdot_fwd", x, x.ld, conv.weight, conv.bias, z, None, M, x.C, self.code))
+        self.output = ("z", z, (x.N, 1, x.H, x.W))
+        needs = x.needs_grad or conv.weight.requires_grad
+        if self.want_grad and needs:
+            self.dout = self.f32(M)
+
+        def rule():
+            if not needs:
+                return
+            nb = lib.mi355_rowreduce_blocks(M)
+            part = self.ws_f32(nb * 2 * x.C)
+            dx = None
+            if x.needs_grad:
+                if self.acc_flag(x):
+                    raise NotImplementedError("logit_conv input with several consumers")
+                dx = self.grad_of(x)
+            self.bwd.append(Launch("mi355_rowdot_bwd", self.dout, x, x.ld, conv.weight, dx, dx.ld if dx is not None else 0, part,
+                                   M, x.C, 0, self.code))
+            if conv.weight.requires_grad:
+                wref, wbeta = self.pgrad(conv.weight)
+                self.bwd.append(Launch("mi355_colsum_finalize", part, nb, 2, x.C, wref, wbeta))
+                if conv.bias is not None:
+                    bref, bbeta = self.pgrad(conv.bias)
+                    self.bwd.append(Launch("mi355_colsum_finalize", self._ws_off(part, x.C * 4), nb, 2 * x.C, 1, bref, bbeta))
+        self.rule(rule)
+        return z
+
+    # ---- classifier heads ---------------------------------------------------------------------------------------------
+    def global_pool(self, x, is_max):
+        v = V(self.f32(x.N * x.C), x.N, x.C)
+        am = self._alloc(x.N * x.C, torch.int32)
+        self.fwd.append(Launch("mi355_global_pool_fwd", x, x.ld, v, am, x.N, x.H * x.W, x.C, 1 if is_max else 0, self.code))
+        v.needs_grad = x.needs_grad
+
+        def rule():
+            if not v.needs_grad:
+                return
+            dv = self.grad_of(v)
+            if self.acc_flag(x):
+                raise NotImplementedError("global_pool input with several consumers")
+            xg = self.grad_of(x)
+            self.bwd.append(Launch("mi355_global_pool_bwd", dv, am, xg, xg.ld, x.N, x.H * x.W, x.C, 1 if is_max else 0, self.code))
+        self.rule(rule)
+        return v
+
+    def linear(self, v, lin, relu=False, is_output=False):
+        O = lin.out_features
+        y = V(self.f32(v.B * O), v.B, O)
+        self.see(lin.weight, lin.bias)
+        self.fwd.append(Launch("mi355_linear_fwd", v, lin.weight, lin.bias, y, v.B, v.F, O, 1 if relu else 0))
+        y.needs_grad = v.needs_grad or lin.weight.requires_grad
+        if is_output:
+            self.output = ("v", y, (v.B, O))
+            if self.want_grad and y.needs_grad:
+                self.dout = self.f32(v.B * O)
+                y._grad = V(self.dout, v.B, O)
+
+        def rule():
+            if not y.needs_grad:
+                return
+            dy = self.grad_of(y)
+            dx = None
+            if v.needs_grad:
+                if self.acc_flag(v):
+                    raise NotImplementedError("linear input with several consumers")
+                dx = self.grad_of(v)
+            dw = db = None
+            beta = 0.0
+            if lin.weight.requires_grad:
+                dw, beta = self.pgrad(lin.weight)
+                if lin.bias is not None:
+                    db, _ = self.pgrad(lin.bias)
+            self.bwd.append(Launch("mi355_linear_bwd", v, lin.weight, y, dy, dx, dw, db, v.B, v.F, O, 1 if relu else 0, beta))
+        self.rule(rule)
+        return y
+
+    def dropout(self, v, p):
+        if not self.training or p == 0.0:
+            return v
+        n = v.B * v.F
+        y = V(self.f32(n), v.B, v.F)
+        mask = self._alloc(n, torch.uint8)
+        seed, counter = self.engine.dropout_stream()
+        self.fwd.append(Launch("mi355_dropout_fwd", v, y, mask, n, float(p), seed, counter))
+        y.needs_grad = v.needs_grad
+
+        def rule():
+            if not y.needs_grad:
+                return
+            dy = self.grad_of(y)
+            if self.acc_flag(v):
+                raise NotImplementedError("dropout input with several consumers")
+            dv = self.grad_of(v)
+            self.bwd.append(Launch("mi355_dropout_bwd", dy, mask, dv, n, float(p)))
+        self.rule(rule)
+        return y
+
+    # ---- nn.Sequential walker with the fusions the reference's blocks allow ----------------------------------------------
+    def seq(self, mods, x, out=None):
+        mods = list(mods)
+        i, n = 0, len(mods)
+        while i < n:
+            m = mods[i]
+            last = lambda j: j >= n - 1
+            up = False
+            if isinstance(m, nn.Upsample):
+                assert float(m.scale_factor) == 2.0 and m.mode == "nearest" and isinstance(mods[i + 1], nn.Conv2d)
+                up, i = True, i + 1
+                m = mods[i]
+            if isinstance(m, nn.Conv2d):
+                nxt = mods[i + 1] if i + 1 < n else None
+                nxt2 = mods[i + 2] if i + 2 < n else None
+                if isinstance(nxt, nn.BatchNorm2d):
+                    act = isinstance(nxt2, nn.ReLU)
+                    step = 3 if act else 2
+                    x = self.conv_bn_act(x, m, nxt, act=act, up=up, out=out if last(i + step - 1) else None)
+                    i += step
+                elif isinstance(nxt, nn.ReLU):
+                    x = self.conv_act(x, m, relu=True, up=up, out=out if last(i + 1) else None)
+                    i += 2
+                else:
+                    x = self.conv_act(x, m, relu=False, up=up, out=out if last(i) else None)
+                    i += 1
+            elif isinstance(m, nn.ConvTranspose2d):
+                x = self.conv_transpose(x, m, out=out if last(i) else None)
+                i += 1
+            elif isinstance(m, nn.BatchNorm2d):
+                act = i + 1 < n and isinstance(mods[i + 1], nn.ReLU)
+                x = self.bn_act(x, m, act=act, out=out if last(i + (1 if act else 0)) else None)
+                i += 2 if act else 1
+            elif isinstance(m, nn.MaxPool2d):
+                k = m.kernel_size if isinstance(m.kernel_size, int) else m.kernel_size[0]
+                s = m.stride if isinstance(m.stride, int) else m.stride[0]
+                p = m.padding if isinstance(m.padding, int) else m.padding[0]
+                x = self.maxpool(x, k, s, p)
+                i += 1
+            elif isinstance(m, nn.Sequential):
+                x = self.seq(m, x, out=out if last(i) else None)
+                i += 1
+            elif isinstance(m, (nn.AdaptiveAvgPool2d, nn.AdaptiveMaxPool2d)):
+                x = self.global_pool(x, isinstance(m, nn.AdaptiveMaxPool2d))
+                i += 1
+            elif isinstance(m, nn.Flatten) or isinstance(m, nn.Identity):
+                i += 1
+            elif isinstance(m, nn.Linear):
+                relu = i + 1 < n and isinstance(mods[i + 1], nn.ReLU)
+                x = self.linear(x, m, relu=relu)
+                i += 2 if relu else 1
+            elif isinstance(m, nn.Dropout):
+                x = self.dropout(x, m.p)
+                i += 1
+            else:
+                raise NotImplementedError(f"no MI355X lowering for {type(m).__name__}")
+        return x
+
+    # ---- finish -------------------------------------------------------------------------------------------------------------
+    def finish(self):
+        for r in reversed(self._rules):
+            r()
+        # resolve _WsOff into (tensor, byte offset) late-bound pairs
+        plan = Plan(self)
+        for lst in (plan.pre, plan.fwd, plan.bwd):
+            for l in lst:
+                if any(isinstance(a, Builder._WsOff) for a in l.args):
+                    l.args = tuple((plan.ws[a.ws.kind], a.off) if isinstance(a, Builder._WsOff) else a for a in l.args)
+        return plan

@@ -1,0 +1,120 @@
+"""Gradient clipping and AdamW on the engine's flat fp32 buffers (utils/helpers.py:251,279,304,
+332-336).  One launch each over contiguous HBM instead of per-tensor loops; lr, step count and
+the clip coefficient stay in device memory so the whole step is graph-capturable."""
+from __future__ import annotations
+
+from typing import Iterable
+
+import torch
+
+from .lib import lib
+
+
+_REGISTRY = {}     # storage pointer of a flat parameter buffer -> (flat_p, flat_g)
+
+
+def register_flat(flat_p, flat_g):
+    _REGISTRY[flat_p.untyped_storage().data_ptr()] = (flat_p, flat_g)
+
+
+def _grad_buffer_of(params):
+    """Locate params inside an engine's flat buffers -> (flat_p, flat_g, lo, hi) or None."""
+    params = list(params)
+    if not params:
+        return None
+    owner = None
+    spans = []
+    for p in params:
+        reg = _REGISTRY.get(p.untyped_storage().data_ptr())
+        if reg is None:
+            return None
+        if owner is None:
+            owner = reg
+        elif reg[0] is not owner[0]:
+            return None
+        off = (p.data_ptr() - owner[0].data_ptr()) // 4
+        spans.append((off, off + p.numel()))
+    spans.sort()
+    for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+        if b0 - a1 > 3 or b0 < a1:          # contiguous up to the 16-byte alignment padding
+            return None
+    return owner[0], owner[1], spans[0][0], spans[-1][1]
+
+
+class _Shared:
+    """Clip state handed from clip_grad_norm_ to the next optimizer.step() on the same flat range."""
+    by_buffer = {}
+
+
+def clip_grad_norm_(parameters: Iterable[torch.Tensor], max_norm: float):
+    """torch.nn.utils.clip_grad_norm_ semantics (global L2 norm, coef = min(1, max/(norm+1e-6))).
+    The scaling itself is folded into the following AdamW launch; returns the norm as a 0-dim
+    device tensor (no host sync)."""
+    params = [p for p in parameters if p.requires_grad]
+    r = _grad_buffer_of(params)
+    if r is None:
+        raise RuntimeError("mi355.optim.clip_grad_norm_ needs the parameters of a mi355 Net (flat storage); "
+                           "there is no torch fallback on this path")
+    base, g, lo, hi = r
+    n = hi - lo
+    lo4 = lo - lo % 4
+    nb = lib.mi355_rowreduce_blocks(hi - lo4)
+    st = _Shared.by_buffer.get((base.data_ptr(), lo, hi))
+    if st is None:
+        dev = base.device
+        st = {"partial": torch.empty(1024, device=dev), "norm": torch.zeros(1, device=dev),
+              "coef": torch.ones(1, device=dev), "finf": torch.zeros(1, device=dev), "fresh": False}
+        _Shared.by_buffer[(base.data_ptr(), lo, hi)] = st
+    lib.mi355_sumsq_partial(g[lo4:hi], st["partial"], hi - lo4)
+    lib.mi355_clip_coef(st["partial"], nb, float(max_norm), 1.0, st["norm"], st["coef"], st["finf"], None)
+    st["fresh"] = True
+    return st["norm"].view(())
+
+
+class AdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW-compatible front (param_groups / lr schedulers work unchanged) whose step()
+    is a single fused launch per parameter group over the engine's flat buffers."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._st = []
+        for gr in self.param_groups:
+            ps = [p for p in gr["params"]]
+            r = _grad_buffer_of(ps)
+            if r is None:
+                raise RuntimeError("mi355.optim.AdamW needs parameters of a mi355 Net that is already on the GPU "
+                                   "(call model.to(device) and run / flatten it first)")
+            base, g, lo, hi = r
+            dev = base.device
+            self._st.append({
+                "p": base, "g": g, "lo": lo, "hi": hi,
+                "m": torch.zeros(hi - lo, device=dev), "v": torch.zeros(hi - lo, device=dev),
+                "lr": torch.tensor([gr["lr"]], dtype=torch.float32, device=dev), "lr_host": gr["lr"],
+                "step": torch.zeros(1, dtype=torch.int32, device=dev),
+                "one": torch.ones(1, device=dev), "scratch": torch.zeros(2, device=dev),
+            })
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for gr, st in zip(self.param_groups, self._st):
+            if gr["lr"] != st["lr_host"]:
+                st["lr"].fill_(gr["lr"])
+                st["lr_host"] = gr["lr"]
+            lo, hi = st["lo"], st["hi"]
+            clip = _Shared.by_buffer.get((st["p"].data_ptr(), lo, hi))
+            coef = st["one"]
+            if clip is not None and clip["fresh"]:
+                coef = clip["coef"]
+                clip["fresh"] = False
+            # tick the device-side step counter (norm/coef outputs go to scratch)
+            lib.mi355_clip_coef(st["scratch"], 0, 0.0, 1.0, st["scratch"], st["scratch"][1:], None, st["step"])
+            b1, b2 = gr["betas"]
+            lib.mi355_adamw(st["p"][lo:hi], st["g"][lo:hi], st["m"], st["v"], hi - lo, st["lr"], float(b1), float(b2),
+                            float(gr["eps"]), float(gr["weight_decay"]), coef, 1.0, None, st["step"])
+        return None
+
+    def zero_grad(self, set_to_none: bool = True):
+        # gradients are (re)written, not accumulated, by every backward plan: dropping the views is enough
+        for gr in self.param_groups:
+            for p in gr["params"]:
+                p.grad = None

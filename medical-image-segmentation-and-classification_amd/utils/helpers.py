@@ -1,0 +1,201 @@
+"""Training driver and factories of the MI355X path — same public names, signatures and
+printed lines as the reference's utils/helpers.py (acc/iou :219-227, factories :124-213,
+train :231-412), executing on the HIP launch-plan engine.
+
+Differences that do not change results: bf16/fp32 compute instead of fp16-autocast + GradScaler
+(no loss scaling needed), the per-step ``loss.item()`` host syncs (helpers.py:337,341) are replaced
+by device-side accumulation read back once per epoch, and model factories construct the local
+classes directly (the reference first tries a torch.hub download, helpers.py:158-166, which has
+no network here)."""
+import math
+import os
+import time
+
+import torch
+import torch.nn as nn
+
+from mi355 import nn as mnn
+from mi355 import optim as moptim
+from mi355.lib import lib
+
+CLASSES = ["COVID", "Healthy", "Non-COVID"]
+
+
+# ---- model factories ---------------------------------------------------------------------------
+def add_dropout_to_fc(model, p=0.5, classes=CLASSES):
+    """Swap the classification layer for Dropout(p) + Linear(in, len(classes)); returns the name of
+    the head attribute ("fc" / "classifier") that stage 1 trains (helpers.py:124-144)."""
+    n_out = len(classes)
+    if hasattr(model, "fc"):
+        model.fc = nn.Sequential(nn.Dropout(p=p), nn.Linear(model.fc.in_features, n_out))
+        return "fc"
+    head = getattr(model, "classifier", None)
+    if isinstance(head, nn.Sequential):
+        kept = list(head.children())
+        last = kept.pop()
+        model.classifier = nn.Sequential(*kept, nn.Dropout(p=p), nn.Linear(last.in_features, n_out))
+        return "classifier"
+    return None
+
+
+def get_class_model(name):
+    """name -> (model, head attribute name); local architectures, random init (helpers.py:170-192)."""
+    from models.classification_models import ResNet, VGG
+    table = {"resnet18": ResNet.ResNet18, "resnet50": ResNet.ResNet50, "vgg16": VGG.VGG16, "vgg19": VGG.VGG19}
+    key = name.lower()
+    if key not in table:
+        raise ValueError(f"Unknown classification model: {name}")
+    model = table[key](num_classes=1000)
+    return model, add_dropout_to_fc(model, p=0.5)
+
+
+def get_seg_model(name):
+    """name -> segmentation model instance (helpers.py:195-213)."""
+    key = name.lower()
+    if key == "attentionunet":
+        from models.segmentation_models.AttentionUNet import AttentionUNet
+        return AttentionUNet()
+    if key == "r2unet":
+        from models.segmentation_models.R2U_Net import R2U_Net
+        return R2U_Net()
+    if key == "r2attunet":
+        from models.segmentation_models.R2AttU_Net import R2AttU_Net
+        return R2AttU_Net()
+    if key == "resnetunet":
+        from models.segmentation_models.ResnetUnet import ResNetUnet
+        return ResNetUnet()
+    raise ValueError(f"Unknown segmentation model: {name}")
+
+
+# ---- metrics --------------------------------------------------------------------------------------
+def acc(logits, y):
+    return (torch.argmax(logits, 1) == y).sum().item(), y.size(0)
+
+
+def _iou_device(pred, mask, t=0.5, is_logit=False):
+    """Whole-batch IoU of helpers.py:223-227 as a 0-dim device tensor (no sync)."""
+    cnt = torch.empty(4, dtype=torch.float32, device=pred.device)
+    lib.mi355_seg_counts(pred.contiguous(), mask.contiguous(), cnt, 1, pred.numel(), 1 if is_logit else 0, float(t))
+    inter, union = cnt[0], cnt[1] + cnt[2] - cnt[0]
+    return inter / (union + 1e-7)
+
+
+def iou(pred, mask, t=0.5):
+    if pred.is_cuda:
+        return _iou_device(pred.float(), mask.float(), t).item()
+    p = (pred > t).float()
+    inter = (p * mask).sum()
+    union = ((p + mask) > 0).float().sum()
+    return (inter / (union + 1e-7)).item()
+
+
+# ---- training ----------------------------------------------------------------------------------------
+def _make_optimizer(params, lr):
+    return moptim.AdamW(params, lr=lr, weight_decay=5e-4)
+
+
+def train(model, train_dl, val_dl, device, epochs, lr, name, save_dir, seg=False, cls_head_name=None):
+    device = torch.device(device)
+    model = model.to(device)
+    if hasattr(model, "engine"):
+        model.engine._check_storage()                 # flat fp32 parameter / gradient buffers
+    criterion = mnn.BCEWithLogitsLoss() if seg else mnn.CrossEntropyLoss(label_smoothing=0.1)
+    STAGE1 = 5
+
+    if seg:
+        optimizer = _make_optimizer(model.parameters(), lr)
+        print(f"Training Segmentation model (all layers unfrozen) with LR: {lr}")
+        scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=epochs)
+    else:
+        print(f"--- STAGE 1: Feature Extraction (Epochs 1-{STAGE1}) ---")
+        for p in model.parameters():
+            p.requires_grad = False
+        head_params = []
+        if cls_head_name:
+            for p in getattr(model, cls_head_name).parameters():
+                p.requires_grad = True
+                head_params.append(p)
+        optimizer = _make_optimizer(head_params, 1e-4)
+        scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=STAGE1)
+
+    best_score = float("inf") if seg else 0.0
+    patience, stale = 10, 0
+    t0 = time.time()
+    n_train, n_val = len(train_dl.dataset), len(val_dl.dataset)
+
+    for epoch in range(1, epochs + 1):
+        if not seg and epoch == STAGE1 + 1:
+            print(f"\n--- STAGE 2: Full Fine-Tuning (Epochs {epoch}-{epochs}) ---")
+            for p in model.parameters():
+                p.requires_grad = True
+            optimizer = _make_optimizer(model.parameters(), lr)
+            scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, mode="max", factor=0.1, patience=3)
+            print(f"Full fine-tuning (all layers unfrozen) with very low LR: {lr}. Using ReduceLROnPlateau scheduler.")
+
+        model.train()
+        loss_sum = torch.zeros((), device=device)
+        hit_sum = torch.zeros((), device=device)
+        seen = 0
+        for x, y in train_dl:
+            x, y = x.to(device, non_blocking=True), y.to(device, non_blocking=True)
+            optimizer.zero_grad(set_to_none=True)
+            out = model(x)
+            if seg and out.dim() == 3:
+                out = out.unsqueeze(1)
+            loss = criterion(out, y)
+            loss.backward()
+            moptim.clip_grad_norm_(model.parameters(), max_norm=1.0)
+            optimizer.step()
+            loss_sum += loss.detach() * x.size(0)
+            if not seg:
+                hit_sum += (torch.argmax(out.detach(), 1) == y).sum()
+                seen += y.size(0)
+
+        model.eval()
+        vloss = torch.zeros((), device=device)
+        vmetric = torch.zeros((), device=device)
+        with torch.no_grad():
+            for x, y in val_dl:
+                x, y = x.to(device), y.to(device)
+                out = model(x)
+                if seg and out.dim() == 3:
+                    out = out.unsqueeze(1)
+                vloss += criterion(out, y) * x.size(0)
+                if seg:
+                    vmetric += _iou_device(out.float(), y.float(), 0.5, is_logit=True)
+                else:
+                    vmetric += (torch.argmax(out, 1) == y).sum()
+
+        # one host read-back per epoch
+        train_loss = loss_sum.item() / n_train
+        val_loss = vloss.item() / n_val
+        if seg:
+            val_iou = vmetric.item() / len(val_dl)
+            score = val_loss
+            print(f"[{name}] Ep{epoch}: TrainLoss {train_loss:.3f} | ValLoss {val_loss:.3f} | IoU {val_iou:.3f}")
+            improved = val_loss < best_score
+        else:
+            train_acc = 100 * hit_sum.item() / max(seen, 1)
+            val_acc = 100 * vmetric.item() / n_val
+            score = val_acc
+            print(f"[{name}] Ep{epoch}: TrainLoss {train_loss:.3f} (Acc {train_acc:.2f}%) | ValLoss {val_loss:.3f} | ValAcc {val_acc:.2f}%")
+            improved = val_acc > best_score
+
+        if seg or epoch <= STAGE1:
+            scheduler.step()
+        else:
+            scheduler.step(score)
+
+        if improved:
+            best_score, stale = score, 0
+            os.makedirs(save_dir, exist_ok=True)
+            fname = f"{name}_best_loss.pt" if seg else f"{name}_best_acc.pt"
+            torch.save(model.state_dict(), os.path.join(save_dir, fname))
+        else:
+            stale += 1
+        if stale >= patience:
+            print(f"Early stopping at epoch {epoch}. Best score: {best_score:.2f}")
+            break
+
+    print(f"Training for {name} finished in {(time.time() - t0) / 60:.2f} minutes.")
+    return best_score

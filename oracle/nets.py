@@ -488,3 +488,35 @@ def is_buffer(key):
 
 def param_keys(sd):
     return [k for k in sd if not is_buffer(k)]
+
+
+def closed_form_fill(sd, salt=0.0):
+    """RNG-free values for an arbitrary module ``state_dict`` (block-level fixtures): returns a new
+    dict with the same keys/shapes.  >1-D tensors ~ U(+-1.5*sqrt(3/fan_in)); BN gamma 1+-0.2;
+    biases/beta +-0.1; running_mean +-0.05; running_var 1+-0.3; counters 0."""
+    out = OrderedDict()
+    for i, (k, v) in enumerate(sd.items()):
+        if not v.is_floating_point():
+            out[k] = torch.zeros_like(v)
+            continue
+        u = (2.0 * _hash01(v.numel(), salt + 3.0 + i) - 1.0).reshape(v.shape)
+        if v.dim() > 1:
+            fan_in = v[0].numel()
+            val = u * 1.5 * math.sqrt(3.0 / fan_in)
+        elif k.endswith("running_var"):
+            val = 1.0 + 0.3 * u
+        elif k.endswith("running_mean"):
+            val = 0.05 * u
+        elif k.endswith("weight"):
+            val = 1.0 + 0.2 * u
+        else:
+            val = 0.1 * u
+        out[k] = val.to(v.dtype)
+    return out
+
+
+def closed_form_tensor(shape, salt):
+    """RNG-free ~N(0,1)-ish tensor (sum of three hashed uniforms, centred and scaled)."""
+    n = int(math.prod(shape))
+    u = _hash01(n, salt) + _hash01(n, salt + 0.37) + _hash01(n, salt + 0.71)
+    return ((u - 1.5) * 2.0).float().reshape(shape)

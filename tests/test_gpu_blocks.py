@@ -1,0 +1,96 @@
+"""-m gpu: the drop-in building blocks vs the REFERENCE blocks' stored results (blocks.npz):
+output, input gradients, parameter gradients and BN running statistics, fp32 mode.
+Blocks are shallow, so fp32 agrees to ~1e-6; the bound asserted is 1e-4 relative-to-max
+(north-star bound 1e-3).  bf16 mode is checked at 3e-2 on outputs."""
+import numpy as np
+import pytest
+import torch
+
+import block_cases as bc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _make(tag):
+    from mi355.engine import Net
+    from models.segmentation_models import _blocks as B
+    from models.classification_models.ResNet import BasicBlock
+    args = bc.CASES[tag][0]
+    if tag == "basic_block":
+        blk, low = B.conv_bn_relu_x2(*args), lambda g, b, xs: g.seq(b, xs[0])
+    elif tag == "UpConv":
+        blk, low = B.UpConv(*args), lambda g, b, xs: g.seq(b.up, xs[0])
+    elif tag == "AttentionGate":
+        blk, low = B.AttentionGate(*args), lambda g, b, xs: g.gate(b, g=xs[0], x=xs[1])
+    elif tag == "Recurrent_block":
+        blk, low = B.Recurrent_block(args[0], args[1], t=args[2]), lambda g, b, xs: b.lower(g, xs[0])
+    elif tag == "RRCNN_block":
+        blk, low = B.RRCNN_block(args[0], args[1], t=args[2]), lambda g, b, xs: b.lower(g, xs[0])
+    else:
+        blk, low = BasicBlock(args[0], args[1], stride=args[2]), lambda g, b, xs: b.lower(g, xs[0])
+    chans = [s[1] for s in bc.CASES[tag][1]]
+
+    class BlockNet(Net):
+        def __init__(self):
+            super().__init__()
+            self.block = blk
+
+        def build(self, g, x):
+            g.want_input_grad(x)
+            xs, o = [], 0
+            for c in chans:
+                xs.append(g.slice_channels(x, o, c) if len(chans) > 1 else x)
+                o += c
+            g.tensor_output(low(g, self.block, xs))
+
+    blk.load_state_dict(bc.fill(tag, blk.state_dict()))
+    return BlockNet()
+
+
+@pytest.mark.parametrize("tag", bc.ORDER)
+def test_block_fp32_matches_reference(tag):
+    z = bc.load()
+    net = _make(tag)
+    net.compute_dtype = torch.float32
+    net = net.to(DEV).train()
+    ins = bc.inputs(tag)
+    x = torch.cat(ins, 1).to(DEV)
+    out = net(x)
+    ref = z[tag + "/out"]
+    w = bc.out_weight(tag, ref.shape)
+    (out * w.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    tol = 1e-4
+    assert np.abs(out.detach().cpu().numpy() - ref).max() < tol * np.abs(ref).max()
+    din = out._mi355_plan.input_grad.view(x.shape).cpu()
+    o = 0
+    for i, t in enumerate(ins):
+        r = z[f"{tag}/din{i}"]
+        got = din[:, o:o + t.shape[1]].numpy()
+        o += t.shape[1]
+        assert np.abs(got - r).max() < tol * np.abs(r).max(), (i, np.abs(got - r).max(), np.abs(r).max())
+    # conv biases in front of a train-mode BN have a mathematically zero gradient (pure round-off in
+    # both implementations), hence the block-wide absolute floor
+    gscale = max(float(np.abs(z[f]).max()) for f in z.files if f.startswith(tag + "/grad/"))
+    for k, p in net.block.named_parameters():
+        got, r, nrm = bc.expected_grad(z, tag, k, p.grad.detach().cpu())
+        assert np.abs(got - r).max() < tol * (np.abs(r).max() + gscale), k
+    for k, v in net.block.state_dict().items():
+        if k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            r = z[f"{tag}/buf/{k}"]
+            assert np.abs(v.cpu().numpy().astype(np.float64) - r).max() < 1e-5 * (np.abs(r).max() + 1e-6), k
+
+
+@pytest.mark.parametrize("tag", bc.ORDER)
+def test_block_bf16_close_to_reference(tag):
+    z = bc.load()
+    net = _make(tag)
+    net.compute_dtype = torch.bfloat16
+    net = net.to(DEV).train()
+    x = torch.cat(bc.inputs(tag), 1).to(DEV)
+    with torch.no_grad():
+        out = net(x)
+    ref = z[tag + "/out"]
+    lim = 6e-2 if tag in ("Recurrent_block", "RRCNN_block") else 3e-2     # 6 / 12 stacked bf16 conv+BN
+    assert np.abs(out.cpu().numpy() - ref).max() < lim * np.abs(ref).max()

@@ -255,7 +255,7 @@ def test_heads_and_losses():
     # dropout: keep-rate and scaling
     nn_ = 1 << 18
     xx = torch.ones(nn_, device=DEV); yy = torch.empty(nn_, device=DEV); mk = torch.empty(nn_, dtype=torch.uint8, device=DEV)
-    lib.mi355_dropout_fwd(xx, yy, mk, nn_, 0.3, 1234)
+    lib.mi355_dropout_fwd(xx, yy, mk, nn_, 0.3, 1234, None)
     dd = torch.empty(nn_, device=DEV)
     lib.mi355_dropout_bwd(xx, mk, dd, nn_, 0.3)
     torch.cuda.synchronize()

@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of one Attention U-Net TRAIN STEP (256x256, bs=32 per GPU, bf16)
+on the MI355X launch-plan path — zero_grad -> forward -> BCEWithLogits -> backward -> [RCCL gradient
+all-reduce] -> clip_grad_norm(1.0) -> AdamW, exactly the per-batch body of the reference's train()
+(utils/helpers.py:320-336) with inputs already resident in HBM.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task description) carrying two extra objects:
+  roofline      dominant kernel: algorithmic FLOPs per launch / average launch duration measured
+                with HIP events on the launch stream in an instrumented replay of the same plan
+  cpu_baseline  the CPU oracle (plain torch fp32 restatement of the reference) timed on this
+                box's host cores on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "medical-image-segmentation-and-classification_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch
+import torch.distributed as dist
+
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # dense MFMA peaks, MI355X_MICROARCH.md
+FWD_GFLOP_PER_IMG = 132.850                       # AttentionUNet 256x256 forward
+TRAIN_GFLOP_PER_IMG = 398.32                      # 3x forward minus the first layer's dgrad
+
+
+def make_batch(b, hw, seed, device):
+    """images ~ N(0,1); target = one filled ellipse per image (25-40 % foreground) — SURVEY.md 8d."""
+    import math
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(b, 3, hw, hw, generator=g)
+    yy, xx = torch.meshgrid(torch.arange(hw, dtype=torch.float32), torch.arange(hw, dtype=torch.float32), indexing="ij")
+    m = torch.zeros(b, 1, hw, hw)
+    for i in range(b):
+        r = torch.rand(4, generator=g)
+        cy, cx = (0.4 + 0.2 * r[0]) * hw, (0.4 + 0.2 * r[1]) * hw
+        area = (0.25 + 0.15 * r[2]) * hw * hw
+        ratio = 0.7 + 0.6 * r[3]
+        a, bb = math.sqrt(area / math.pi * ratio), math.sqrt(area / math.pi / ratio)
+        m[i, 0] = ((((yy - cy) / a) ** 2 + ((xx - cx) / bb) ** 2) <= 1.0).float()
+    return x.to(device), m.to(device)
+
+
+def profile_plan(plan, x, stream, reps=2):
+    """Instrumented replay: HIP events around every launch of the forward and backward plans."""
+    fwd, bwd = plan.bind(stream)
+    agg = {}
+    for _ in range(reps):
+        recs = []
+        for i, (fn, args, name, l) in enumerate(list(fwd) + list(bwd)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(x.data_ptr(), *args[1:]) if i == 0 else fn(*args)
+            e1.record()
+            if rc:
+                raise RuntimeError(f"{name} failed rc={rc}")
+            recs.append((l, e0, e1))
+        torch.cuda.synchronize()
+        for l, e0, e1 in recs:
+            key = l.tag or l.name
+            a = agg.setdefault(key, [0.0, 0, 0.0])
+            a[0] += e0.elapsed_time(e1)
+            a[1] += 1
+            a[2] += l.flops
+    return agg
+
+
+def cpu_baseline(hw, bs, steps):
+    """Reference-equivalent CPU path (oracle/) on this box's host cores: fp32, one warm-up + `steps` timed."""
+    from oracle import nets, train as otrain
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("BENCH_CPU_THREADS", "16"))))   # a 1-GPU box owns a 16-core share
+    torch.set_num_threads(cores)
+    sd = nets.default_init_state("AttentionUNet", seed=0)
+    x, y = otrain.synthetic_batch(bs, hw, seed=0)
+    opt = otrain.AdamW(nets.param_keys(sd), 1e-6)
+    otrain.train_step("AttentionUNet", sd, x, y, opt, True)
+    t0 = time.time()
+    for _ in range(steps):
+        otrain.train_step("AttentionUNet", sd, x, y, opt, True)
+    dt = (time.time() - t0) / steps
+    return {"value": round(bs / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"AttentionUNet {hw}x{hw} fp32 train step, bs={bs} (per-image rate), 1 warm-up + {steps} timed steps"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--model", default="AttentionUNet")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--graph", type=int, default=0, help="capture the step into a hipGraph (1) or run eagerly (0)")
+    ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel time table to stderr")
+    args = ap.parse_args()
+
+    t_start = time.perf_counter()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from mi355 import nn as mnn, optim as moptim
+    from mi355.dp import DataParallel
+    from utils.helpers import get_seg_model
+
+    torch.manual_seed(0)
+    model = get_seg_model({"AttentionUNet": "attentionunet", "R2AttU_Net": "r2attunet", "R2U_Net": "r2unet"}[args.model])
+    model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model = model.to(device).train()
+    model.engine._check_storage()
+    dp = DataParallel(model) if world > 1 else None
+    crit = mnn.BCEWithLogitsLoss()
+    opt = moptim.AdamW(model.parameters(), lr=1e-6, weight_decay=5e-4)
+    inv_scale = dp.inv_scale if dp is not None else 1.0
+    opt.inv_scale = inv_scale          # gradient averaging over ranks is folded into clip + AdamW
+    x, y = make_batch(args.batch, args.size, seed=rank, device=device)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = model(x)
+        loss = crit(out, y)
+        loss.backward()
+        moptim.clip_grad_norm_(model.parameters(), max_norm=1.0, inv_scale=inv_scale)
+        opt.step()
+        return loss
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    log("model / optimizer / batch ready; first step (builds the launch plan)")
+    step()
+    torch.cuda.synchronize()
+    log(f"first step done; plan launches fwd/bwd = {[p.n_launches for p in model.engine.plans.values()]}")
+    runner = step
+    if args.graph:
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            static_loss = step()
+        runner = lambda: (g.replay(), static_loss)[1]
+
+    for _ in range(args.warmup):
+        loss = runner()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = runner()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    final_loss = float(loss.detach())
+    log(f"timed region done: {elapsed / args.steps * 1e3:.2f} ms/step")
+
+    result = None
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = args.batch * world * args.steps / elapsed
+        result = {
+            "metric": "images/sec (train step) Attention U-Net 256x256 bs=32/GPU",
+            "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.model} {args.size}x{args.size} train step (fwd+BCE+bwd+clip+AdamW), "
+                                   f"bs={args.batch}/GPU, NHWC {args.dtype} activations, fp32 master weights",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": bool(args.graph),
+                       "final_loss": round(final_loss, 5)},
+        }
+        step_tflops = TRAIN_GFLOP_PER_IMG * (args.size / 256) ** 2 * value / world / 1e3
+        result["config"]["step_mfma_frac"] = round(step_tflops / PEAK_TFLOPS[args.dtype], 4)
+
+    # ---- per-kernel roofline (instrumented replay of the same plan, rank 0) -----------------------------
+    if rank == 0 and not args.no_profile:
+        plan = [p for p in model.engine.plans.values() if p.training and p.dout is not None][0]
+        agg = profile_plan(plan, x, torch.cuda.current_stream().cuda_stream)
+        total = sum(v[0] for v in agg.values())
+        ranked = sorted(agg.items(), key=lambda kv: -kv[1][0])
+        if args.kernel_table:
+            print(f"{'kernel / launcher':58s} {'ms/step':>9s} {'launches':>8s} {'TFLOP/s':>9s} {'share':>6s}", file=sys.stderr)
+            reps = 2
+            for k, (ms_, n, fl) in ranked[:25]:
+                tf = fl / (ms_ * 1e-3) / 1e12 if fl else 0.0
+                print(f"{k:58s} {ms_ / reps:9.3f} {n // reps:8d} {tf:9.1f} {ms_ / total:6.1%}", file=sys.stderr)
+            print(f"{'sum of plan launches':58s} {total / reps:9.3f}", file=sys.stderr)
+        k, (ms_, n, fl) = ranked[0]
+        if fl:
+            ach = fl / (ms_ * 1e-3) / 1e12
+            peak = PEAK_TFLOPS[args.dtype]
+            result["roofline"] = {"bound": "mfma", "kernel": k, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                                  "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": n // 2,
+                                  "avg_launch_ms": round(ms_ / n, 4), "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3),
+                                  "share_of_plan_time": round(ms_ / total, 3)}
+        else:
+            result["roofline"] = {"bound": "hbm", "kernel": k, "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None,
+                                  "traffic": None, "avg_launch_ms": round(ms_ / n, 4)}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        log("per-kernel profile done; timing the CPU oracle baseline")
+        result["cpu_baseline"] = cpu_baseline(args.size, 2, 2)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

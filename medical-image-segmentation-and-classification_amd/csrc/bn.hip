@@ -22,6 +22,29 @@ template <typename T> struct BnStatsOp {
   }
 };
 
+
+// ---- folding per-workgroup partials -----------------------------------------------------------------
+// Finalize kernels run one 256-thread workgroup per 32 channels: thread (bl, cl) sums partial rows
+// b = bl, bl+8, ... for channel c0+cl (a wave reads four 128-B channel runs per step), then the 8
+// row-lanes are folded through LDS.  `q` selects the quantity, `nq` the quantities per block row.
+#define FIN_CH 32
+#define FIN_BL 8
+__device__ __forceinline__ double fold_partials(const float* __restrict__ partial, int nblocks, int rowlen, int off, int C,
+                                                double* red) {
+  const int cl = threadIdx.x % FIN_CH, bl = threadIdx.x / FIN_CH;
+  const int c = blockIdx.x * FIN_CH + cl;
+  double s = 0;
+  if (c < C)
+    for (int b = bl; b < nblocks; b += FIN_BL) s += (double)partial[(size_t)b * rowlen + off + c];
+  red[bl * FIN_CH + cl] = s;
+  __syncthreads();
+  double t = 0;
+  if (bl == 0)
+    for (int k = 0; k < FIN_BL; ++k) t += red[k * FIN_CH + cl];
+  __syncthreads();
+  return t;     // valid for threads with bl == 0
+}
+
 extern "C" int mi355_rowreduce_blocks(long long M) { return rowreduce_blocks(M); }
 
 extern "C" int mi355_bn_stats(const void* x, float* partial, long long M, int C, int ld, int dtype, mi355_stream_t s) {
@@ -39,14 +62,13 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int nblock
                                    float* __restrict__ rmean, float* __restrict__ rvar, int64_t* nbt, float momentum,
                                    float eps, float* __restrict__ scale, float* __restrict__ shift,
                                    float* __restrict__ mean_out, float* __restrict__ invstd_out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ double red[FIN_CH * FIN_BL];
+  const double s = fold_partials(partial, nblocks, 2 * C, 0, C, red);
+  const double q = fold_partials(partial, nblocks, 2 * C, C, C, red);
+  const int c = blockIdx.x * FIN_CH + threadIdx.x;
+  if (threadIdx.x >= FIN_CH) return;
   if (c == 0 && nbt) *nbt += 1;
   if (c >= C) return;
-  double s = 0, q = 0;
-  for (int b = 0; b < nblocks; ++b) {
-    s += (double)partial[((size_t)b * 2 + 0) * C + c];
-    q += (double)partial[((size_t)b * 2 + 1) * C + c];
-  }
   const double mean = s / M;
   double var = q / M - mean * mean;
   if (var < 0) var = 0;
@@ -68,7 +90,7 @@ extern "C" int mi355_bn_finalize(const float* partial, int nblocks, long long M,
                                  float momentum, float eps, float* scale, float* shift, float* mean, float* invstd,
                                  mi355_stream_t s) {
   MI355_CHECK_ARG(partial && gamma && beta && scale && shift && mean && invstd, "bn_finalize: null pointer");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, (hipStream_t)s, partial, nblocks, (double)M, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, FIN_CH)), dim3(FIN_CH * FIN_BL), 0, (hipStream_t)s, partial, nblocks, (double)M, C,
                      gamma, beta, running_mean, running_var, nbt, momentum, eps, scale, shift, mean, invstd);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
@@ -181,13 +203,11 @@ extern "C" int mi355_bn_bwd_reduce(const void* dy, int lddy, const void* y, int 
 
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, float* __restrict__ sums,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta, float accf) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s0 = 0, s1 = 0;
-  for (int b = 0; b < nblocks; ++b) {
-    s0 += (double)partial[((size_t)b * 2 + 0) * C + c];
-    s1 += (double)partial[((size_t)b * 2 + 1) * C + c];
-  }
+  __shared__ double red[FIN_CH * FIN_BL];
+  const double s0 = fold_partials(partial, nblocks, 2 * C, 0, C, red);
+  const double s1 = fold_partials(partial, nblocks, 2 * C, C, C, red);
+  const int c = blockIdx.x * FIN_CH + threadIdx.x;
+  if (threadIdx.x >= FIN_CH || c >= C) return;
   sums[c] = (float)s0;
   sums[C + c] = (float)s1;
   if (dbeta) dbeta[c] = (accf != 0.f ? accf * dbeta[c] : 0.f) + (float)s0;
@@ -197,7 +217,7 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nb
 extern "C" int mi355_bn_bwd_finalize(const float* partial, int nblocks, int C, float* sums, float* dgamma, float* dbeta,
                                      float acc, mi355_stream_t s) {
   MI355_CHECK_ARG(partial && sums, "bn_bwd_finalize: null pointer");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, (hipStream_t)s, partial, nblocks, C, sums,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, FIN_CH)), dim3(FIN_CH * FIN_BL), 0, (hipStream_t)s, partial, nblocks, C, sums,
                      dgamma, dbeta, acc);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
@@ -285,17 +305,17 @@ extern "C" int mi355_colsum(const void* x, int ld, float* partial, long long M, 
 
 __global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nblocks, int stride, int C,
                                        float* __restrict__ out, float accf) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s0 = 0;
-  for (int b = 0; b < nblocks; ++b) s0 += (double)partial[(size_t)b * stride * C + c];
+  __shared__ double red[FIN_CH * FIN_BL];
+  const double s0 = fold_partials(partial, nblocks, stride * C, 0, C, red);
+  const int c = blockIdx.x * FIN_CH + threadIdx.x;
+  if (threadIdx.x >= FIN_CH || c >= C) return;
   out[c] = (accf != 0.f ? accf * out[c] : 0.f) + (float)s0;
 }
 
 extern "C" int mi355_colsum_finalize(const float* partial, int nblocks, int stride, int C, float* out, float acc,
                                      mi355_stream_t s) {
   MI355_CHECK_ARG(partial && out, "colsum_finalize: null pointer");
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, (hipStream_t)s, partial, nblocks, stride, C,
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(C, FIN_CH)), dim3(FIN_CH * FIN_BL), 0, (hipStream_t)s, partial, nblocks, stride, C,
                      out, acc);
   MI355_LAUNCH_CHECK();
   return MI355_OK;

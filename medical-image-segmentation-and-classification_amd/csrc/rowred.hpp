@@ -121,12 +121,14 @@ static inline int rowred_launch(const Op& op, long long M, int C, float* partial
 template <typename T, typename Op>
 __global__ __launch_bounds__(256) void rowmap_kernel(Op op, long long M, int cp) {
   constexpr int EPC = 16 / (int)sizeof(T);
-  const long long total = M * cp;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const long long r = i / cp;
-    const int c = (int)(i - r * cp);
-    op.apply((size_t)r, c * EPC);
-  }
+  // tpr lanes cover one pixel row's chunks (strided when cp > 256); rp rows per workgroup pass.
+  // No per-element division: the (row, chunk) split is fixed per thread.
+  const int tpr = cp < 256 ? cp : 256;
+  const int rp = 256 / tpr;
+  const int tx = threadIdx.x % tpr, ty = threadIdx.x / tpr;
+  if (ty >= rp) return;
+  for (long long r = (long long)blockIdx.x * rp + ty; r < M; r += (long long)gridDim.x * rp)
+    for (int c = tx; c < cp; c += tpr) op.apply((size_t)r, c * EPC);
 }
 
 template <typename T, typename Op>
@@ -137,8 +139,9 @@ static inline int rowmap_launch(const Op& op, long long M, int C, hipStream_t s)
     return MI355_ERR_ARG;
   }
   const int cp = C / epc;
-  long long blocks = (M * cp + 255) / 256;
-  if (blocks > 256 * 16) blocks = 256 * 16;
+  const int rp = 256 / (cp < 256 ? cp : 256);
+  long long blocks = (M + rp - 1) / rp;
+  if (blocks > 256 * 16) blocks = 256 * 16;     // grid-stride beyond 16 workgroups per CU
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL((rowmap_kernel<T, Op>), dim3((int)blocks), dim3(256), 0, s, op, M, cp);
   hipError_t e = hipGetLastError();

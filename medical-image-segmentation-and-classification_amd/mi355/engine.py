@@ -125,7 +125,7 @@ class Engine:
         if x.dtype != torch.float32 or not x.is_contiguous():
             x = x.float().contiguous()
         pre_fwd, _ = plan.bind(self._stream())
-        fn, args, name = pre_fwd[0]                      # mi355_pack_input_nchw reads the caller's tensor in place
+        fn, args, name, _ = pre_fwd[0]                   # mi355_pack_input_nchw reads the caller's tensor in place
         rc = fn(x.data_ptr(), *args[1:])
         if rc:
             raise RuntimeError(f"{name} failed (rc={rc}): {lib.raw('mi355_last_error')().decode()}")

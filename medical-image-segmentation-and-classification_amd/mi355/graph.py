@@ -94,10 +94,13 @@ class Ws:
 
 
 class Launch:
-    __slots__ = ("name", "args")
+    """One C-ABI call.  `flops` is the ALGORITHMIC work of the launch (2*MACs of the convolution it
+    implements, real channel counts) when it is a GEMM-shaped kernel, else 0; `tag` names the kernel
+    variant the launcher dispatches to (for per-kernel roofline accounting in bench.py)."""
+    __slots__ = ("name", "args", "flops", "tag")
 
-    def __init__(self, name, *args):
-        self.name, self.args = name, args
+    def __init__(self, name, *args, flops=0, tag=""):
+        self.name, self.args, self.flops, self.tag = name, args, flops, tag
 
 
 class Plan:
@@ -149,7 +152,7 @@ class Plan:
             conv.append(stream)
             if len(conv) != len(fn.argtypes):
                 raise TypeError(f"{l.name}: built {len(conv)} args, ABI takes {len(fn.argtypes)}")
-            out.append((fn, tuple(conv), l.name))
+            out.append((fn, tuple(conv), l.name, l))
         return out
 
     def bind(self, stream):
@@ -160,7 +163,7 @@ class Plan:
 
     @staticmethod
     def _run(calls):
-        for fn, args, name in calls:
+        for fn, args, name, _ in calls:
             rc = fn(*args)
             if rc:
                 raise RuntimeError(f"{name} failed (rc={rc}): {lib.raw('mi355_last_error')().decode()}")
@@ -360,8 +363,9 @@ class Builder:
         wf, wb = self.packs(conv, x.C)
         y = out if out is not None else self.new_tensor(x.N, Ho, Wo, Co)
         assert (y.N, y.H, y.W, y.C) == (x.N, Ho, Wo, Co)
+        flops = 2 * x.N * Ho * Wo * Co * k * k * conv.in_channels
         self.fwd.append(Launch("mi355_conv2d_igemm", x, wf, conv.bias, y, x.N, x.H, x.W, x.C, x.ld, Ho, Wo, Co, y.ld,
-                               k, k, s, 1, -p, 1, 1 if up else 0, 0, self.code))
+                               k, k, s, 1, -p, 1, 1 if up else 0, 0, self.code, flops=flops, tag=self.igemm_tag(Co, x.C)))
         y.needs_grad = x.needs_grad or conv.weight.requires_grad
 
         def bwd(dy, bias_done=False):
@@ -369,7 +373,7 @@ class Builder:
                 splits = lib.mi355_conv2d_wgrad_splits(x.N, Ho, Wo, x.C, Co, k, k)
                 ws = self.ws_bytes(splits * Co * k * k * x.C * 4)
                 self.bwd.append(Launch("mi355_conv2d_wgrad", x, dy, ws, splits, x.N, x.H, x.W, x.C, x.ld, Ho, Wo, Co, dy.ld,
-                                       k, k, s, p, 1 if up else 0, self.code))
+                                       k, k, s, p, 1 if up else 0, self.code, flops=flops, tag=self.wgrad_tag(Co, x.C)))
                 ref, beta = self.pgrad(conv.weight)
                 self.bwd.append(Launch("mi355_conv2d_wgrad_reduce", ws, splits, ref, Co, x.C, conv.in_channels, k, k, 0, beta))
             if conv.bias is not None and conv.bias.requires_grad and not bias_done:
@@ -378,7 +382,7 @@ class Builder:
                 if up:
                     tmp = self.new_tensor(x.N, 2 * x.H, 2 * x.W, x.C)
                     self.bwd.append(Launch("mi355_conv2d_igemm", dy, wb, None, tmp, x.N, Ho, Wo, Co, dy.ld, 2 * x.H, 2 * x.W,
-                                           x.C, tmp.ld, k, k, 1, -1, p, s, 0, 0, self.code))
+                                           x.C, tmp.ld, k, k, 1, -1, p, s, 0, 0, self.code, flops=flops, tag=self.igemm_tag(x.C, Co)))
                     acc = self.acc_flag(x)
                     xg = self.grad_of(x)
                     self.bwd.append(Launch("mi355_upsample2_bwd", tmp, tmp.ld, xg, xg.ld, x.N, x.H, x.W, x.C, acc, self.code))
@@ -386,8 +390,19 @@ class Builder:
                     acc = self.acc_flag(x)
                     xg = self.grad_of(x)
                     self.bwd.append(Launch("mi355_conv2d_igemm", dy, wb, None, xg, x.N, Ho, Wo, Co, dy.ld, x.H, x.W, x.C,
-                                           xg.ld, k, k, 1, -1, p, s, 0, acc, self.code))
+                                           xg.ld, k, k, 1, -1, p, s, 0, acc, self.code, flops=flops, tag=self.igemm_tag(x.C, Co)))
         return y, bwd
+
+    def igemm_tag(self, co, ci):
+        """Kernel variant mi355_conv2d_igemm dispatches to (mirrors csrc/conv_igemm.hip)."""
+        bn = 128 if co % 128 == 0 else (64 if co % 64 == 0 else 32)
+        if self.dtype == torch.bfloat16:
+            return f"conv_igemm_kernel<bf16,{bn},{64 if ci % 64 == 0 else 32}>"
+        return f"conv_igemm_kernel<f32,{bn},16>"
+
+    def wgrad_tag(self, co, ci):
+        t = "bf16" if self.dtype == torch.bfloat16 else "f32"
+        return f"conv_wgrad_kernel<{t},{128 if co % 128 == 0 else 64},{128 if ci % 128 == 0 else 64}>"
 
     def bias_grad_from(self, dy, bias):
         nb = lib.mi355_rowreduce_blocks(dy.M)

@@ -46,7 +46,7 @@ class _Shared:
     by_buffer = {}
 
 
-def clip_grad_norm_(parameters: Iterable[torch.Tensor], max_norm: float):
+def clip_grad_norm_(parameters: Iterable[torch.Tensor], max_norm: float, inv_scale: float = 1.0):
     """torch.nn.utils.clip_grad_norm_ semantics (global L2 norm, coef = min(1, max/(norm+1e-6))).
     The scaling itself is folded into the following AdamW launch; returns the norm as a 0-dim
     device tensor (no host sync)."""
@@ -66,7 +66,7 @@ def clip_grad_norm_(parameters: Iterable[torch.Tensor], max_norm: float):
               "coef": torch.ones(1, device=dev), "finf": torch.zeros(1, device=dev), "fresh": False}
         _Shared.by_buffer[(base.data_ptr(), lo, hi)] = st
     lib.mi355_sumsq_partial(g[lo4:hi], st["partial"], hi - lo4)
-    lib.mi355_clip_coef(st["partial"], nb, float(max_norm), 1.0, st["norm"], st["coef"], st["finf"], None)
+    lib.mi355_clip_coef(st["partial"], nb, float(max_norm), float(inv_scale), st["norm"], st["coef"], st["finf"], None)
     st["fresh"] = True
     return st["norm"].view(())
 
@@ -78,6 +78,7 @@ class AdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._st = []
+        self.inv_scale = 1.0          # e.g. 1/world_size: gradients are summed, not averaged, by the all-reduce
         for gr in self.param_groups:
             ps = [p for p in gr["params"]]
             r = _grad_buffer_of(ps)
@@ -110,7 +111,7 @@ class AdamW(torch.optim.Optimizer):
             lib.mi355_clip_coef(st["scratch"], 0, 0.0, 1.0, st["scratch"], st["scratch"][1:], None, st["step"])
             b1, b2 = gr["betas"]
             lib.mi355_adamw(st["p"][lo:hi], st["g"][lo:hi], st["m"], st["v"], hi - lo, st["lr"], float(b1), float(b2),
-                            float(gr["eps"]), float(gr["weight_decay"]), coef, 1.0, None, st["step"])
+                            float(gr["eps"]), float(gr["weight_decay"]), coef, float(self.inv_scale), None, st["step"])
         return None
 
     def zero_grad(self, set_to_none: bool = True):

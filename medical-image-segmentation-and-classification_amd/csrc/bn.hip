@@ -24,18 +24,28 @@ template <typename T> struct BnStatsOp {
 
 
 // ---- folding per-workgroup partials -----------------------------------------------------------------
-// Finalize kernels run one 256-thread workgroup per 32 channels: thread (bl, cl) sums partial rows
-// b = bl, bl+8, ... for channel c0+cl (a wave reads four 128-B channel runs per step), then the 8
+// Finalize kernels run one 1024-thread workgroup per 32 channels: thread (bl, cl) sums partial rows
+// b = bl, bl+32, ... for channel c0+cl (a wave reads four 128-B channel runs per step), then the 8
 // row-lanes are folded through LDS.  `q` selects the quantity, `nq` the quantities per block row.
 #define FIN_CH 32
-#define FIN_BL 8
+#define FIN_BL 32
 __device__ __forceinline__ double fold_partials(const float* __restrict__ partial, int nblocks, int rowlen, int off, int C,
                                                 double* red) {
   const int cl = threadIdx.x % FIN_CH, bl = threadIdx.x / FIN_CH;
   const int c = blockIdx.x * FIN_CH + cl;
   double s = 0;
-  if (c < C)
-    for (int b = bl; b < nblocks; b += FIN_BL) s += (double)partial[(size_t)b * rowlen + off + c];
+  if (c < C) {
+    double s1 = 0, s2 = 0, s3 = 0;
+    int b = bl;
+    for (; b + 3 * FIN_BL < nblocks; b += 4 * FIN_BL) {      // four independent loads in flight
+      s += (double)partial[(size_t)b * rowlen + off + c];
+      s1 += (double)partial[(size_t)(b + FIN_BL) * rowlen + off + c];
+      s2 += (double)partial[(size_t)(b + 2 * FIN_BL) * rowlen + off + c];
+      s3 += (double)partial[(size_t)(b + 3 * FIN_BL) * rowlen + off + c];
+    }
+    for (; b < nblocks; b += FIN_BL) s += (double)partial[(size_t)b * rowlen + off + c];
+    s += s1 + s2 + s3;
+  }
   red[bl * FIN_CH + cl] = s;
   __syncthreads();
   double t = 0;
@@ -122,18 +132,25 @@ template <typename T> struct BnActOp {
   const T* res; int ldr;
   T* y; int ldy;
   int act;
+  float sc[EPC], sh[EPC], sc2[EPC];
+  __device__ void load_cols(int c0) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      sc[e] = scale ? scale[c0 + e] : 1.f;
+      sh[e] = scale ? shift[c0 + e] : 0.f;
+      sc2[e] = x2 ? scale2[c0 + e] : 0.f;
+      if (x2) sh[e] += shift2[c0 + e];
+    }
+  }
   __device__ void apply(size_t row, int c0) const {
     const Vec16<T> v = ld16<T>(x + row * ldx + c0);
     float f[EPC];
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-      f[e] = to_f32<T>(v.v[e]);
-      if (scale) f[e] = f[e] * scale[c0 + e] + shift[c0 + e];
-    }
+    for (int e = 0; e < EPC; ++e) f[e] = to_f32<T>(v.v[e]) * sc[e] + sh[e];
     if (x2) {
       const Vec16<T> v2 = ld16<T>(x2 + row * ldx2 + c0);
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) f[e] += to_f32<T>(v2.v[e]) * scale2[c0 + e] + shift2[c0 + e];
+      for (int e = 0; e < EPC; ++e) f[e] += to_f32<T>(v2.v[e]) * sc2[e];
     }
     if (res) {
       const Vec16<T> vr = ld16<T>(res + row * ldr + c0);

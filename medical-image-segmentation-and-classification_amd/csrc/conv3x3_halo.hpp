@@ -1,0 +1,228 @@
+// 3x3 / stride-1 / pad-1 convolution (forward and data gradient) for bf16 on gfx950:
+// implicit GEMM with a HALO-PATCH A operand.
+//
+// A workgroup owns a TH x TW spatial tile (256 pixels) of one image times BN output channels.
+// For every 32-channel slab of Ci the (TH+2) x (TW+2) input patch is streamed into LDS ONCE by
+// LDS-DMA and then serves all nine taps (the tap only shifts the fragment read address), so the
+// activation is fetched ~1.3x instead of 9x per K sweep; only the [BN][32] weight slab of each tap
+// is re-streamed (3-deep ring, counted s_waitcnt vmcnt across raw s_barriers).  L2->LDS traffic per
+// MFMA drops ~3x versus the im2col-style gather, DMA-issue and address VALU per MFMA ~3x.
+//   patch image : pixel-linear, 64 B per pixel, 16-B chunk slot = chunk ^ ((pixel >> 2) & 3)
+//                 (source-side swizzle: conflict-free ds_read_b128 for 32 consecutive pixels)
+//   weight slab : [BN rows][64 B], slot = chunk ^ ((row >> 2) & 3)
+#pragma once
+#include "common.hpp"
+
+template <int BN, int TH, int TW> struct HaloCfg {
+  static constexpr int NPIX = (TH + 2) * (TW + 2);
+  static constexpr int P_IT = ((NPIX + 15) / 16 + 3) / 4;
+  static constexpr int PATCH_BYTES = P_IT * 4 * 1024;
+  static constexpr int RING = 2 * PATCH_BYTES + 3 * BN * 64;
+  static constexpr int C_BYTES = TH * TW * (BN * 2 + 16);
+  static constexpr int LDS_BYTES = RING > C_BYTES ? RING : C_BYTES;
+};
+
+template <int BN, int TH, int TW>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvArgs a) {
+  typedef bf16_t T;
+  constexpr int BK = 32, EPC = 8, BM = TH * TW;
+  static_assert(BM == 256, "tile must hold 256 pixels");
+  constexpr int PH = TH + 2, PW = TW + 2, NPIX = PH * PW;
+  constexpr int PIXB = BK * 2;                       // 64 B per pixel / weight row
+  constexpr int P_INSTR = (NPIX + 15) / 16;          // 1-KiB DMA instructions per patch
+  constexpr int P_IT = (P_INSTR + 3) / 4;            // per wave
+  constexpr int PATCH_BYTES = P_IT * 4 * 1024;
+  constexpr int B_IT = BN / 16 / 4;                  // DMA instructions per wave per weight slab
+  constexpr int B_BYTES = BN * PIXB;
+  constexpr int NSB = 3;
+  constexpr int WM = (BN == 128) ? 2 : 4, WN = 4 / WM;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int MI = WTM / 32, NI = WTN / 32;
+  constexpr int C_PITCH = BN * 2 + 16;
+  static_assert(HaloCfg<BN, TH, TW>::PATCH_BYTES == PATCH_BYTES && NSB == 3, "host/device LDS layout mismatch");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // HaloCfg::LDS_BYTES (> 64 KiB: dynamic)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r32 = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int NT = a.Co / BN, TXN = a.Wi / TW, TYN = a.Hi / TH;
+  int t = blockIdx.x;
+  const int nt = t % NT; t /= NT;
+  const int tx = t % TXN; t /= TXN;
+  const int ty = t % TYN;
+  const int n = t / TYN;
+  const int y0 = ty * TH, x0 = tx * TW, n0 = nt * BN;
+  const T* __restrict__ in = reinterpret_cast<const T*>(a.in);
+  const T* __restrict__ wk = reinterpret_cast<const T*>(a.wk);
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+  const bool flip = a.kmul < 0;                      // data gradient: taps mirrored
+
+  // ---- DMA lane geometry ----------------------------------------------------------------------
+  const int lrow = lane >> 2, slot = lane & 3;
+  const T* p_src[P_IT];                              // per-lane source of each patch instruction (chunk applied)
+#pragma unroll
+  for (int i = 0; i < P_IT; ++i) {
+    const int q = (wave + 4 * i) * 16 + lrow;        // patch pixel index
+    const int py = q / PW, px = q - py * PW;
+    const int yy = y0 - 1 + py, xx = x0 - 1 + px;
+    const bool ok = q < NPIX && (unsigned)yy < (unsigned)a.Hi && (unsigned)xx < (unsigned)a.Wi;
+    p_src[i] = ok ? in + ((size_t)(n * a.Hi + yy) * a.Wi + xx) * a.ldi + (slot ^ ((q >> 2) & 3)) * EPC : nullptr;
+  }
+  const size_t wrow = (size_t)9 * a.Ci;
+  const T* b_src[B_IT];
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) {
+    const int row = (wave + 4 * i) * 16 + lrow;
+    b_src[i] = wk + (size_t)(n0 + row) * wrow + (slot ^ ((row >> 2) & 3)) * EPC;
+  }
+  unsigned char* const patch0 = lds;
+  unsigned char* const bring = lds + 2 * PATCH_BYTES;
+
+  auto issue_patch = [&](int buf, int c0) {
+    unsigned char* dst = patch0 + buf * PATCH_BYTES;
+#pragma unroll
+    for (int i = 0; i < P_IT; ++i) {
+      const char* p = p_src[i] ? reinterpret_cast<const char*>(p_src[i] + c0) : zero + slot * 16;
+      __builtin_amdgcn_global_load_lds((gl_void_t*)p, (lds_void_t*)(dst + (wave + 4 * i) * 1024), 16, 0, 0);
+    }
+  };
+  auto issue_b = [&](int stage, int tap, int c0) {
+    unsigned char* dst = bring + stage * B_BYTES;
+    const size_t off = (size_t)tap * a.Ci + c0;
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i)
+      __builtin_amdgcn_global_load_lds((gl_void_t*)(b_src[i] + off), (lds_void_t*)(dst + (wave + 4 * i) * 1024), 16, 0, 0);
+  };
+
+  // ---- fragment geometry ------------------------------------------------------------------------
+  int q0[MI];                                        // patch pixel of (tile pixel, tap (0,0))
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int p = wm * WTM + mi * 32 + r32;
+    const int py = p / TW, px = p - py * TW;
+    q0[mi] = py * PW + px;
+  }
+  int brow[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) brow[ni] = wn * WTN + ni * 32 + r32;
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int nC = a.Ci / BK;
+  const int S = nC * 9;
+  // issue-side iterator for weight slabs
+  int itap = 0, ic0 = 0, issued = 0, istage = 0;
+  auto issue_next_b = [&]() {
+    issue_b(istage, itap, ic0);
+    istage = (istage + 1 == NSB) ? 0 : istage + 1;
+    if (++itap == 9) {
+      itap = 0;
+      ic0 += BK;
+    }
+    ++issued;
+  };
+  issue_patch(0, 0);
+  issue_next_b();
+  if (S > 1) {
+    issue_next_b();
+    wait_vmcnt<B_IT>();
+  } else {
+    wait_vmcnt<0>();
+  }
+  __builtin_amdgcn_s_barrier();
+
+  int stage = 0, tap = 0, chunk = 0;
+  for (int s = 0; s < S; ++s) {
+    const bool more_b = issued < S;
+    if (more_b) issue_next_b();
+    const bool patch_now = tap == 0 && chunk + 1 < nC;
+    if (patch_now) issue_patch((chunk + 1) & 1, (chunk + 1) * BK);
+
+    const unsigned char* pa = patch0 + (chunk & 1) * PATCH_BYTES;
+    const unsigned char* pb = bring + stage * B_BYTES;
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const int toff = flip ? (2 - kh) * PW + (2 - kw) : kh * PW + kw;
+#pragma unroll
+    for (int kq = 0; kq < 2; ++kq) {
+      const int c = kq * 2 + h;
+      uint4 af[MI], bf[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int q = q0[mi] + toff;
+        af[mi] = *reinterpret_cast<const uint4*>(pa + q * PIXB + ((c ^ ((q >> 2) & 3)) << 4));
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        bf[ni] = *reinterpret_cast<const uint4*>(pb + brow[ni] * PIXB + ((c ^ ((brow[ni] >> 2) & 3)) << 4));
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) Frag<T>::mma(af[mi], bf[ni], acc[mi][ni]);
+    }
+    // the next slab (and, in order before it, any older patch) must have landed; what may stay in
+    // flight: the slab issued this step and a patch issued this step or the one before
+    const bool patch_pending = (tap <= 1) && chunk + 1 < nC;
+    if (more_b) {
+      if (patch_pending) wait_vmcnt<B_IT + P_IT>(); else wait_vmcnt<B_IT>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    stage = (stage + 1 == NSB) ? 0 : stage + 1;
+    if (++tap == 9) {
+      tap = 0;
+      ++chunk;
+    }
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------------------
+  T* __restrict__ out = reinterpret_cast<T*>(a.out);
+  float bcol[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) bcol[ni] = a.bias ? a.bias[n0 + brow[ni]] : 0.f;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        *reinterpret_cast<T*>(lds + row * C_PITCH + brow[ni] * 2) = from_f32<T>(acc[mi][ni][r] + bcol[ni]);
+      }
+  __syncthreads();
+  constexpr int CPRC = BN / EPC;
+  for (int id = tid; id < BM * CPRC; id += 256) {
+    const int row = id / CPRC, c = id - row * CPRC;
+    const int py = row / TW, px = row - py * TW;
+    T* p = out + ((size_t)(n * a.Ho + y0 + py) * a.Wo + x0 + px) * a.ldo + n0 + c * EPC;
+    Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(lds + row * C_PITCH + c * 16);
+    if (a.accumulate) {
+      const Vec16<T> o = ld16<T>(p);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) v.v[e] = from_f32<T>(to_f32<T>(v.v[e]) + to_f32<T>(o.v[e]));
+    }
+    st16<T>(p, v);
+  }
+}
+
+template <int BN, int TH, int TW>
+static int launch_halo(const ConvArgs& a, hipStream_t s) {
+  const int grid = a.N * (a.Hi / TH) * (a.Wi / TW) * (a.Co / BN);
+  constexpr int lds_bytes = HaloCfg<BN, TH, TW>::LDS_BYTES;
+  static bool configured = false;        // immutable after the first call (set before any launch of this variant)
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BN, TH, TW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       lds_bytes);
+    if (e != hipSuccess) MI355_FAIL((int)e, "conv3x3_halo: cannot reserve %d B of LDS: %s", lds_bytes, hipGetErrorString(e));
+    configured = true;
+  }
+  hipLaunchKernelGGL((conv3x3_halo_kernel<BN, TH, TW>), dim3(grid), dim3(256), lds_bytes, s, a);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}

@@ -11,6 +11,7 @@
 //   bf16: v_mfma_f32_32x32x16_bf16, BK = 64 (or 32) channels per slab
 //   fp32: v_mfma_f32_32x32x2_f32 (exact fmaf chain), BK = 16
 #include "common.hpp"
+#include <stdlib.h>
 
 struct ConvArgs {
   const void* in;
@@ -251,6 +252,222 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   }
 }
 
+// ==============================================================================================
+// bf16 fast path: the same tiling with the operand tiles streamed by LDS-DMA
+// (global_load_lds_dwordx4: 16 B per lane, per-lane gather address, no VGPR staging, no ds_write)
+// into an NS-deep LDS ring.  Tile k+NS-1 is issued while tile k is multiplied; a COUNTED
+// s_waitcnt vmcnt leaves the newest tiles in flight across the raw s_barrier, so HBM/L2 latency
+// is hidden behind NS-1 MFMA phases instead of one.  The XOR swizzle moves to the SOURCE side
+// (the DMA writes lane-linear: lane (row, slot) fetches chunk slot ^ swz(row) of its pixel row);
+// padding / stride-hole rows read a 256-B zero page.
+// ==============================================================================================
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gl_void_t;
+__device__ uint4 g_zero_page[16];
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+
+template <int BN, int BK, int NS>
+__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvArgs a) {
+  typedef bf16_t T;
+  constexpr int BM = 128;
+  constexpr int EPC = 8;
+  constexpr int CPR = BK / EPC;               // 16-B chunks per LDS row (4 or 8)
+  constexpr int P = BK * 2;                   // row pitch in bytes (64 or 128)
+  constexpr int RPBS = (P == 128) ? 1 : 2;
+  constexpr int RPW = 64 / CPR;               // rows covered by one wave-instruction (1 KiB)
+  constexpr int A_IT = BM / RPW / 4;          // DMA instructions per wave per A tile
+  constexpr int B_IT = BN / RPW / 4;
+  static_assert(B_IT >= 1, "every wave must issue the same number of DMA instructions");
+  constexpr int WM = (BN == 32) ? 4 : 2, WN = 4 / WM;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int MI = WTM / 32, NI = WTN / 32;
+  constexpr int KQ = CPR / 2;
+  constexpr int A_BYTES = BM * P, B_BYTES = BN * P, STAGE = A_BYTES + B_BYTES;
+  constexpr int C_PITCH = BN * 2 + 16;
+  constexpr int C_BYTES = BM * C_PITCH;
+  constexpr int LDS_BYTES = (NS * STAGE > C_BYTES) ? NS * STAGE : C_BYTES;
+  constexpr int PER_TILE = A_IT + B_IT;       // DMA instructions per wave per K tile
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r32 = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int NT = a.Co / BN;
+  const int mt = blockIdx.x / NT, nt = blockIdx.x - mt * NT;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const T* __restrict__ in = reinterpret_cast<const T*>(a.in);
+  const T* __restrict__ wk = reinterpret_cast<const T*>(a.wk);
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+  // lane geometry inside one DMA instruction: RPW rows x CPR chunk slots
+  const int lrow = lane / CPR, slot = lane % CPR;
+  int a_nb[A_IT], a_hs[A_IT], a_ws[A_IT], a_ck[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int row = (wave + 4 * i) * RPW + lrow;
+    a_ck[i] = (slot ^ ((row >> RPBS) & (CPR - 1))) * EPC;     // source chunk (swizzle on the source side)
+    const int m = m0 + row;
+    if (m < a.M) {
+      const int n = m / a.HoWo;
+      const int rem = m - n * a.HoWo;
+      const int ho = rem / a.Wo;
+      const int wo = rem - ho * a.Wo;
+      a_nb[i] = n * a.Hi;
+      a_hs[i] = ho * a.mul + a.off;
+      a_ws[i] = wo * a.mul + a.off;
+    } else {
+      a_nb[i] = 0;
+      a_hs[i] = -(1 << 28);
+      a_ws[i] = 0;
+    }
+  }
+  const int taps = a.KH * a.KW;
+  const size_t wrow = (size_t)taps * a.Ci;
+  const T* b_ptr[B_IT];
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) {
+    const int row = (wave + 4 * i) * RPW + lrow;
+    b_ptr[i] = wk + (size_t)(n0 + row) * wrow + (slot ^ ((row >> RPBS) & (CPR - 1))) * EPC;
+  }
+  const int dmask = (1 << a.dshift) - 1;
+
+  auto issue_tile = [&](int stage, int kh, int kw, int c0) {
+    unsigned char* la = lds + stage * STAGE;
+    unsigned char* lb = la + A_BYTES;
+    const int dh = kh * a.kmul, dw = kw * a.kmul;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      int th = a_hs[i] + dh, tw = a_ws[i] + dw;
+      bool ok = ((th | tw) & dmask) == 0;
+      th >>= a.dshift;
+      tw >>= a.dshift;
+      ok = ok && (unsigned)th < (unsigned)a.Hlog && (unsigned)tw < (unsigned)a.Wlog;
+      th >>= a.up;
+      tw >>= a.up;
+      const char* p = ok ? reinterpret_cast<const char*>(in + ((size_t)(a_nb[i] + th) * a.Wi + tw) * a.ldi + c0 + a_ck[i])
+                         : zero + slot * 16;
+      __builtin_amdgcn_global_load_lds((gl_void_t*)p, (lds_void_t*)(la + (wave + 4 * i) * 1024), 16, 0, 0);
+    }
+    const size_t boff = (size_t)(kh * a.KW + kw) * a.Ci + c0;
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i)
+      __builtin_amdgcn_global_load_lds((gl_void_t*)(b_ptr[i] + boff), (lds_void_t*)(lb + (wave + 4 * i) * 1024), 16, 0, 0);
+  };
+  auto swz = [](int row, int c) { return (c ^ ((row >> RPBS) & (CPR - 1))) << 4; };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int KT = taps * (a.Ci / BK);
+  // tile iterator of the ISSUE side
+  int ikh = 0, ikw = 0, ic0 = 0, issued = 0;
+  auto advance = [&]() {
+    ic0 += BK;
+    if (ic0 == a.Ci) {
+      ic0 = 0;
+      if (++ikw == a.KW) {
+        ikw = 0;
+        ++ikh;
+      }
+    }
+  };
+  // prologue: NS-1 tiles in flight
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) {
+    if (issued < KT) {
+      issue_tile(s, ikh, ikw, ic0);
+      advance();
+      ++issued;
+    }
+  }
+  if (KT >= NS - 1) wait_vmcnt<(NS - 2) * PER_TILE>(); else wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+
+  int stage = 0, istage = NS - 1;
+  for (int kt = 0; kt < KT; ++kt) {
+    const bool more = issued < KT;
+    if (more) {
+      issue_tile(istage, ikh, ikw, ic0);
+      advance();
+      ++issued;
+      istage = (istage + 1 == NS) ? 0 : istage + 1;
+    }
+    const unsigned char* la = lds + stage * STAGE;
+    const unsigned char* lb = la + A_BYTES;
+#pragma unroll
+    for (int kq = 0; kq < KQ; ++kq) {
+      const int c = kq * 2 + h;
+      uint4 af[MI], bf[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int row = wm * WTM + mi * 32 + r32;
+        af[mi] = *reinterpret_cast<const uint4*>(la + row * P + swz(row, c));
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int row = wn * WTN + ni * 32 + r32;
+        bf[ni] = *reinterpret_cast<const uint4*>(lb + row * P + swz(row, c));
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) Frag<T>::mma(af[mi], bf[ni], acc[mi][ni]);
+    }
+    stage = (stage + 1 == NS) ? 0 : stage + 1;
+    // tile kt+1 must have landed: everything but the newest NS-2 tiles (fewer at the tail)
+    if (more) wait_vmcnt<(NS - 2) * PER_TILE>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+  }
+
+  // ---- epilogue: bias, bf16 rounding, LDS-staged 16-B row-contiguous stores ---------------------
+  T* __restrict__ out = reinterpret_cast<T*>(a.out);
+  float bcol[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) bcol[ni] = a.bias ? a.bias[n0 + wn * WTN + ni * 32 + r32] : 0.f;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int col = wn * WTN + ni * 32 + r32;
+        *reinterpret_cast<T*>(lds + row * C_PITCH + col * 2) = from_f32<T>(acc[mi][ni][r] + bcol[ni]);
+      }
+  __syncthreads();
+  constexpr int CPRC = BN / EPC;
+  for (int id = tid; id < BM * CPRC; id += 256) {
+    const int row = id / CPRC, c = id - row * CPRC;
+    const int m = m0 + row;
+    if (m < a.M) {
+      T* p = out + (size_t)m * a.ldo + n0 + c * EPC;
+      Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(lds + row * C_PITCH + c * 16);
+      if (a.accumulate) {
+        const Vec16<T> o = ld16<T>(p);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v.v[e] = from_f32<T>(to_f32<T>(v.v[e]) + to_f32<T>(o.v[e]));
+      }
+      st16<T>(p, v);
+    }
+  }
+}
+
+template <int BN, int BK, int NS>
+static int launch_dma(const ConvArgs& a, hipStream_t s) {
+  const int grid = ceil_div(a.M, 128) * (a.Co / BN);
+  hipLaunchKernelGGL((conv_igemm_dma_kernel<BN, BK, NS>), dim3(grid), dim3(256), 0, s, a);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+#include "conv3x3_halo.hpp"
+
 template <typename T, int BN, int BK>
 static int launch(const ConvArgs& a, hipStream_t s) {
   const int grid = ceil_div(a.M, 128) * (a.Co / BN);
@@ -295,7 +512,34 @@ extern "C" int mi355_conv2d_igemm(const void* in, const void* wk, const float* b
   hipStream_t st = (hipStream_t)s;
   if (dtype == MI355_BF16) {
     MI355_CHECK_ARG(Ci % 32 == 0, "conv2d_igemm: bf16 needs Ci %% 32 == 0 (got %d)", Ci);
-    if (Ci % 64 == 0) return launch_bn<bf16_t, 64>(a, st);
+    static const int variant = getenv("MI355_IGEMM_VARIANT") ? atoi(getenv("MI355_IGEMM_VARIANT")) : 1;
+    if (variant == 0) {          // register-staged reference kernel
+      if (Ci % 64 == 0) return launch_bn<bf16_t, 64>(a, st);
+      return launch_bn<bf16_t, 32>(a, st);
+    }
+    // 3x3 stride-1 pad-1 forward / data gradient on tile-divisible images: halo-patch kernel
+    const bool is3x3s1 = KH == 3 && KW == 3 && mul == 1 && div == 1 && !up && Hi == Ho && Wi == Wo &&
+                         ((kmul == 1 && off == -1) || (kmul == -1 && off == 1));
+    if (variant == 6 && is3x3s1 && Co % 64 == 0) {   // experimental: measured slower than the DMA ring (barrier-bound)
+      if (Wi % 32 == 0 && Hi % 8 == 0) return Co % 128 == 0 ? launch_halo<128, 8, 32>(a, st) : launch_halo<64, 8, 32>(a, st);
+      if (Wi % 16 == 0 && Hi % 16 == 0) return Co % 128 == 0 ? launch_halo<128, 16, 16>(a, st) : launch_halo<64, 16, 16>(a, st);
+    }
+    // measured on MI355X (AttentionUNet shapes): the 2-deep BK=64 ring (2 workgroups/CU) wins for 128-wide
+    // tiles, the 3-deep BK=32 ring (3-4 workgroups/CU) for 64-wide tiles and for Ci % 64 != 0
+    const bool k64 = Ci % 64 == 0;
+    if (Co % 128 == 0) {
+      if (variant == 2 && k64) return launch_dma<128, 64, 3>(a, st);
+      if (variant == 3) return launch_dma<128, 32, 4>(a, st);
+      if (variant == 5 || !k64) return launch_dma<128, 32, 3>(a, st);
+      return launch_dma<128, 64, 2>(a, st);
+    }
+    if (Co % 64 == 0) {
+      if (variant == 2 && k64) return launch_dma<64, 64, 3>(a, st);
+      if (variant == 3) return launch_dma<64, 32, 4>(a, st);
+      if (variant == 4 && k64) return launch_dma<64, 64, 2>(a, st);
+      return launch_dma<64, 32, 3>(a, st);
+    }
+    if (k64) return launch_dma<32, 64, 3>(a, st);
     return launch_bn<bf16_t, 32>(a, st);
   } else if (dtype == MI355_F32) {
     MI355_CHECK_ARG(Ci % 16 == 0, "conv2d_igemm: fp32 needs Ci %% 16 == 0 (got %d)", Ci);

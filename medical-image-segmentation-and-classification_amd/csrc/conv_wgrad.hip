@@ -267,27 +267,55 @@ extern "C" int mi355_conv2d_wgrad(const void* x, const void* dy, float* ws, int 
 }
 
 // dw[co][ci][kh][kw] (or [ci][co][kh][kw] when transposed) = beta*dw + sum_s ws[s][co][tap][ci]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, float* __restrict__ dw, int Co, int Ci,
-                                    int Ci_real, int taps, int transposed, float beta) {
+// One workgroup per (co, 32-channel ci tile).  Thread (kl, cl) sums splits kl, kl+8, ... of channel
+// ci0+cl for every tap (slab reads are 128-B ci-contiguous runs, 8 split lanes keep loads in flight),
+// the 8 split lanes are folded through LDS, and the result is written transposed so that the
+// parameter-gradient stores are contiguous runs of 32*taps floats.
+#define WR_CI 32
+#define WR_KL 8
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, float* __restrict__ dw, int Co,
+                                                           int Ci, int Ci_real, int taps, int transposed, float beta) {
+  extern __shared__ float tile[];                 // [WR_KL][taps][WR_CI + 1]
+  const int ciTiles = (Ci + WR_CI - 1) / WR_CI;
+  const int co = blockIdx.x / ciTiles, ci0 = (blockIdx.x % ciTiles) * WR_CI;
   const size_t total = (size_t)Co * taps * Ci;
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  const int ci = idx % Ci;
-  const int tap = (idx / Ci) % taps;
-  const int co = idx / ((size_t)Ci * taps);
-  if (ci >= Ci_real) return;
-  float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += ws[(size_t)k * total + idx];
-  const size_t o = transposed ? ((size_t)ci * Co + co) * taps + tap : ((size_t)co * Ci_real + ci) * taps + tap;
-  dw[o] = (beta != 0.f ? beta * dw[o] : 0.f) + s;
+  const int cl = threadIdx.x % WR_CI, kl = threadIdx.x / WR_CI;
+  const int ci = ci0 + cl;
+  const int tstride = taps * (WR_CI + 1);
+  for (int tap = 0; tap < taps; ++tap) {
+    float s0 = 0.f, s1 = 0.f;
+    if (ci < Ci) {
+      const float* p = ws + ((size_t)co * taps + tap) * Ci + ci;
+      int k = kl;
+      for (; k + WR_KL < splits; k += 2 * WR_KL) {
+        s0 += p[(size_t)k * total];
+        s1 += p[(size_t)(k + WR_KL) * total];
+      }
+      if (k < splits) s0 += p[(size_t)k * total];
+    }
+    tile[kl * tstride + tap * (WR_CI + 1) + cl] = s0 + s1;
+  }
+  __syncthreads();
+  const int n = taps * WR_CI;
+  for (int t = threadIdx.x; t < n; t += 256) {
+    const int c2 = t / taps, tap = t - c2 * taps;
+    const int cc = ci0 + c2;
+    if (cc >= Ci_real) continue;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < WR_KL; ++k) s += tile[k * tstride + tap * (WR_CI + 1) + c2];
+    const size_t o = transposed ? ((size_t)cc * Co + co) * taps + tap : ((size_t)co * Ci_real + cc) * taps + tap;
+    dw[o] = (beta != 0.f ? beta * dw[o] : 0.f) + s;
+  }
 }
 
 extern "C" int mi355_conv2d_wgrad_reduce(const float* ws, int splits, float* dw, int Co, int Ci, int Ci_real, int KH,
                                          int KW, int transposed, float beta, mi355_stream_t s) {
   MI355_CHECK_ARG(ws && dw && splits >= 1, "conv2d_wgrad_reduce: bad arguments");
-  const size_t total = (size_t)Co * KH * KW * Ci;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)s, ws, splits, dw, Co, Ci,
-                     Ci_real, KH * KW, transposed, beta);
+  const int taps = KH * KW;
+  const int ciTiles = (Ci + WR_CI - 1) / WR_CI;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(Co * ciTiles), dim3(256), WR_KL * taps * (WR_CI + 1) * sizeof(float), (hipStream_t)s,
+                     ws, splits, dw, Co, Ci, Ci_real, taps, transposed, beta);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }

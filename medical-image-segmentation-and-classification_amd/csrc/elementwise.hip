@@ -313,6 +313,7 @@ extern "C" int mi355_upsample2_bwd(const void* dy, int lddy, void* dx, int lddx,
 template <typename T> struct AddOp {
   static constexpr int EPC = 16 / (int)sizeof(T);
   const T* a; int lda; const T* b; int ldb; T* y; int ldy;
+  __device__ void load_cols(int) {}
   __device__ void apply(size_t row, int c0) const {
     Vec16<T> v = ld16<T>(a + row * lda + c0);
     if (b) {
@@ -338,6 +339,7 @@ extern "C" int mi355_add(const void* a, int lda, const void* b, int ldb, void* y
 template <typename T> struct ReluOp {
   static constexpr int EPC = 16 / (int)sizeof(T);
   const T* g; int ldg; const T* y; int ldy; T* o; int ldo;   // g == nullptr: forward (o = relu(y))
+  __device__ void load_cols(int) {}
   __device__ void apply(size_t row, int c0) const {
     const Vec16<T> yv = ld16<T>(y + row * ldy + c0);
     Vec16<T> r;

@@ -138,6 +138,7 @@ extern "C" int mi355_rowdot_bwd(const float* dz, const void* x, int ldx, const f
 template <typename T> struct GateMulOp {
   static constexpr int EPC = 16 / (int)sizeof(T);
   const T* x; int ldx; const float* z; const float* scale; const float* shift; T* y; int ldy;
+  __device__ void load_cols(int) {}
   __device__ void apply(size_t row, int c0) const {
     const float psi = 1.f / (1.f + __expf(-(z[row] * scale[0] + shift[0])));
     Vec16<T> v = ld16<T>(x + row * ldx + c0);

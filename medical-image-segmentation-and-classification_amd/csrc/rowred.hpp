@@ -117,7 +117,7 @@ static inline int rowred_launch(const Op& op, long long M, int C, float* partial
   return MI355_OK;
 }
 
-// Elementwise skeleton over [M][C]: Op::apply(row, c0) handles one 16-B chunk.
+// Elementwise skeleton over [M][C]: Op::load_cols(c0) once per thread, Op::apply(row, c0) per 16-B chunk.
 template <typename T, typename Op>
 __global__ __launch_bounds__(256) void rowmap_kernel(Op op, long long M, int cp) {
   constexpr int EPC = 16 / (int)sizeof(T);
@@ -127,8 +127,10 @@ __global__ __launch_bounds__(256) void rowmap_kernel(Op op, long long M, int cp)
   const int rp = 256 / tpr;
   const int tx = threadIdx.x % tpr, ty = threadIdx.x / tpr;
   if (ty >= rp) return;
-  for (long long r = (long long)blockIdx.x * rp + ty; r < M; r += (long long)gridDim.x * rp)
-    for (int c = tx; c < cp; c += tpr) op.apply((size_t)r, c * EPC);
+  for (int c = tx; c < cp; c += tpr) {          // one trip unless a row has more than 256 chunks
+    op.load_cols(c * EPC);                       // per-channel constants live in registers for the whole band
+    for (long long r = (long long)blockIdx.x * rp + ty; r < M; r += (long long)gridDim.x * rp) op.apply((size_t)r, c * EPC);
+  }
 }
 
 template <typename T, typename Op>

@@ -200,6 +200,15 @@ class Net(nn.Module):
             object.__setattr__(self, "_mi355_engine", e)
         return e
 
+    def _apply(self, fn, recurse=True):
+        """.to()/.cuda() re-create parameter storage: re-establish the flat fp32 buffers right away so
+        that optimisers built from ``model.parameters()`` see the engine's storage."""
+        r = super()._apply(fn, recurse)
+        p = next(self.parameters(), None)
+        if p is not None and p.device.type == "cuda" and p.dtype == torch.float32:
+            self.engine.flatten()
+        return r
+
     def build(self, g: graph.Builder, x: graph.T):
         raise NotImplementedError
 

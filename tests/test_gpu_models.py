@@ -111,7 +111,7 @@ def test_fp32_model_matches_reference_golden_and_oracle(name):
     assert max_g <= max(RTOL, 5 * max_c), (max_g, max_c)
     gn = np.array([float(params[k].grad.double().norm()) for k in names])
     big = z["grad_norm"] > 1e-5 * z["grad_norm"].max()
-    assert np.allclose(gn[big], z["grad_norm"][big], rtol=max(5e-3, 8 * med_c)), np.abs(gn[big] / z["grad_norm"][big] - 1).max()
+    assert np.allclose(gn[big], z["grad_norm"][big], rtol=max(5e-3, 15 * med_c)), np.abs(gn[big] / z["grad_norm"][big] - 1).max()
     # BN buffers after one train-mode forward
     msd = m.state_dict()
     for k, l2 in zip([str(s) for s in z["buffer_names"]], z["buffer_l2_after"]):
@@ -124,7 +124,7 @@ def test_fp32_model_matches_reference_golden_and_oracle(name):
     total = moptim.clip_grad_norm_(m.parameters(), 1.0)
     opt.step()
     torch.cuda.synchronize()
-    assert abs(float(total) - float(z["total_grad_norm"])) < max(5e-3, 8 * med_c) * float(z["total_grad_norm"])
+    assert abs(float(total) - float(z["total_grad_norm"])) < max(5e-3, 15 * med_c) * float(z["total_grad_norm"])
     numel = np.array([params[k].numel() for k in names])
     l2 = np.array([float(params[k].detach().double().norm()) for k in names])
     assert np.all(np.abs(l2 - z["param_l2_after"]) <= 1e-5 * l2 + 0.3 * lr * np.sqrt(numel))

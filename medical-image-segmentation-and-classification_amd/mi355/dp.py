@@ -27,6 +27,7 @@ class DataParallel:
         self._sched = {}
         self.comm_stream = None
         self.inv_scale = 1.0 / self.world
+        self.run_calls = graph.Plan._run      # injectable (CPU tests replace the kernel launcher)
         if self.world > 1:
             self.engine.bwd_runner = self._run_backward
 
@@ -62,24 +63,27 @@ class DataParallel:
     def _run_backward(self, plan, stream):
         calls = plan.bind(stream)[1]
         buckets = self.schedule(plan)
-        if not self.overlap or not torch.cuda.is_available():
-            graph.Plan._run(calls)
-            for _, lo, hi in buckets:
+        if not self.overlap or not self.engine.flat_g.is_cuda:
+            start = 0
+            for ready, lo, hi in buckets:         # same order as the overlapped path, executed serially
+                self.run_calls(calls[start:ready + 1])
+                start = ready + 1
                 self._allreduce(lo, hi)
+            self.run_calls(calls[start:])
             return
         if self.comm_stream is None:
             self.comm_stream = torch.cuda.Stream()
         main = torch.cuda.current_stream()
         start = 0
         for ready, lo, hi in buckets:
-            graph.Plan._run(calls[start:ready + 1])
+            self.run_calls(calls[start:ready + 1])
             start = ready + 1
             ev = torch.cuda.Event()
             ev.record(main)
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
                 self._allreduce(lo, hi)
-        graph.Plan._run(calls[start:])
+        self.run_calls(calls[start:])
         main.wait_stream(self.comm_stream)
 
     def __call__(self, x):

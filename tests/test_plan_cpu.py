@@ -1,0 +1,106 @@
+"""CPU: host-side logic of the launch-plan builder (no kernels run): state_dict compatibility with
+the reference layouts, ABI arity of every emitted launch, gradient bookkeeping (first write /
+accumulate), frozen-parameter pruning, eval plans."""
+import pytest
+import torch
+
+from mi355 import graph
+from mi355.lib import lib, available
+from oracle import nets
+
+pytestmark = pytest.mark.skipif(not available(), reason="libmi355conv.so not built")
+
+
+def _models():
+    from models.segmentation_models.AttentionUNet import AttentionUNet
+    from models.segmentation_models.R2AttU_Net import R2AttU_Net
+    from models.segmentation_models.R2U_Net import R2U_Net
+    from models.classification_models.ResNet import ResNet18, ResNet50
+    from models.classification_models.VGG import VGG16, VGG19
+    return {"AttentionUNet": (AttentionUNet, (2, 3, 32, 32)), "R2AttU_Net": (R2AttU_Net, (1, 3, 32, 32)),
+            "R2U_Net": (R2U_Net, (1, 3, 32, 32)), "ResNet18": (lambda: ResNet18(3), (2, 3, 64, 64)),
+            "ResNet50": (lambda: ResNet50(3), (2, 3, 64, 64)), "VGG16": (lambda: VGG16(3), (2, 3, 32, 32)),
+            "VGG19": (lambda: VGG19(3), (2, 3, 32, 32))}
+
+
+@pytest.mark.parametrize("name", list(_models()))
+def test_state_dict_layout_matches_reference(name):
+    ctor, _ = _models()[name]
+    sd = ctor().state_dict()
+    spec = nets.spec(name)
+    assert set(sd) == set(spec)
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(spec[k][0]), k
+
+
+@pytest.mark.parametrize("name", ["AttentionUNet", "R2AttU_Net", "ResNet18", "VGG16"])
+def test_plan_structure(name):
+    ctor, shape = _models()[name]
+    net = ctor().train()
+    eng = net.engine
+    eng.flatten()
+    plan = eng.plan_for(shape, True, True, torch.float32)
+    fwd, bwd = plan.bind(0)                     # resolves every pointer and checks ABI arity; launches nothing
+    assert len(fwd) == plan.n_launches[0] and len(bwd) == plan.n_launches[1] and len(bwd) > 0
+    params = list(net.parameters())
+    assert {id(p) for p in plan.grad_params} == {id(p) for p in params}
+    # each parameter: exactly one overwriting (beta/acc == 0) gradient write, the rest accumulate
+    first, later = {}, {}
+    for l in plan.bwd:
+        for i, a in enumerate(l.args):
+            if isinstance(a, graph.GRef):
+                beta = l.args[-1] if l.name in ("mi355_conv2d_wgrad_reduce", "mi355_colsum_finalize", "mi355_linear_bwd",
+                                                "mi355_bn_bwd_finalize") else None
+                assert beta is not None, l.name
+                d = first if beta == 0.0 else later
+                d[id(a.param)] = d.get(id(a.param), 0) + 1
+    for p in params:
+        assert first.get(id(p), 0) >= 1, "parameter never written"
+    if name == "R2AttU_Net":
+        assert sum(later.values()) > 0            # shared recurrent weights accumulate over 6 applications
+    elif name == "ResNet18":
+        assert sum(later.values()) == 2           # bn1 (gamma, beta) is applied twice (ResNet.py:130,134)
+    else:
+        assert sum(later.values()) == 0
+    # eval plan: no backward, running-stat coefficients instead of batch statistics
+    net.eval()
+    ev = eng.plan_for(shape, False, False, torch.float32)
+    assert ev.n_launches[1] == 0
+    names = {l.name for l in ev.fwd}
+    assert "mi355_bn_stats" not in names and ("mi355_bn_eval_coeffs" in names or name == "VGG16")
+
+
+def test_frozen_backbone_prunes_backward():
+    """Stage 1 of the classification protocol (helpers.py:258-283): only the head trains."""
+    from models.classification_models.ResNet import ResNet18
+    from utils.helpers import add_dropout_to_fc
+    net = ResNet18(num_classes=1000)
+    head = add_dropout_to_fc(net, p=0.5)
+    assert head == "fc"
+    for p in net.parameters():
+        p.requires_grad = False
+    for p in net.fc.parameters():
+        p.requires_grad = True
+    net.train()
+    net.engine.flatten()
+    plan = net.engine.plan_for((2, 3, 64, 64), True, True, torch.float32)
+    assert {id(p) for p in plan.grad_params} == {id(p) for p in net.fc.parameters()}
+    assert all(l.name in ("mi355_linear_bwd", "mi355_dropout_bwd") for l in plan.bwd), {l.name for l in plan.bwd}
+    assert any(l.name == "mi355_dropout_fwd" for l in plan.fwd)
+
+
+def test_concat_is_free_and_slices_share_storage():
+    from models.segmentation_models.AttentionUNet import AttentionUNet
+    net = AttentionUNet().train()
+    net.engine.flatten()
+    plan = net.engine.plan_for((1, 3, 32, 32), True, True, torch.bfloat16)
+    assert not any("cat" in l.name for l in plan.fwd)
+    # UpConv's bn_act and the gate multiply write into the two halves of one buffer (ld = 2C)
+    gate = [l for l in plan.fwd if l.name == "mi355_gate_mul_fwd"]
+    assert len(gate) == 4 and all(l.args[6] == 2 * l.args[8] for l in gate)   # ldy == 2*C
+
+
+def test_no_cpu_fallback():
+    from models.segmentation_models.AttentionUNet import AttentionUNet
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        AttentionUNet()(torch.zeros(1, 3, 32, 32))

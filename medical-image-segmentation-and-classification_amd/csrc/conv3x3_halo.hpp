@@ -7,6 +7,7 @@
 // activation is fetched ~1.3x instead of 9x per K sweep; only the [BN][32] weight slab of each tap
 // is re-streamed (3-deep ring, counted s_waitcnt vmcnt across raw s_barriers).  L2->LDS traffic per
 // MFMA drops ~3x versus the im2col-style gather, DMA-issue and address VALU per MFMA ~3x.
+//   (nearest x2 up-sampling of the input is folded into the patch gather: source pixel = logical >> 1)
 //   patch image : pixel-linear, 64 B per pixel, 16-B chunk slot = chunk ^ ((pixel >> 2) & 3)
 //                 (source-side swizzle: conflict-free ds_read_b128 for 32 consecutive pixels)
 //   weight slab : [BN rows][64 B], slot = chunk ^ ((row >> 2) & 3)
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvArgs a) 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r32 = lane & 31, h = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
-  const int NT = a.Co / BN, TXN = a.Wi / TW, TYN = a.Hi / TH;
+  const int NT = a.Co / BN, TXN = a.Wo / TW, TYN = a.Ho / TH;     // tiles walk the OUTPUT grid (= input grid, x2 if `up`)
   int t = blockIdx.x;
   const int nt = t % NT; t /= NT;
   const int tx = t % TXN; t /= TXN;
@@ -64,9 +65,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvArgs a) 
   for (int i = 0; i < P_IT; ++i) {
     const int q = (wave + 4 * i) * 16 + lrow;        // patch pixel index
     const int py = q / PW, px = q - py * PW;
-    const int yy = y0 - 1 + py, xx = x0 - 1 + px;
-    const bool ok = q < NPIX && (unsigned)yy < (unsigned)a.Hi && (unsigned)xx < (unsigned)a.Wi;
-    p_src[i] = ok ? in + ((size_t)(n * a.Hi + yy) * a.Wi + xx) * a.ldi + (slot ^ ((q >> 2) & 3)) * EPC : nullptr;
+    const int yy = y0 - 1 + py, xx = x0 - 1 + px;          // on the logical (post-upsample) grid
+    const bool ok = q < NPIX && (unsigned)yy < (unsigned)a.Hlog && (unsigned)xx < (unsigned)a.Wlog;
+    p_src[i] = ok ? in + ((size_t)(n * a.Hi + (yy >> a.up)) * a.Wi + (xx >> a.up)) * a.ldi + (slot ^ ((q >> 2) & 3)) * EPC
+                  : nullptr;
   }
   const size_t wrow = (size_t)9 * a.Ci;
   const T* b_src[B_IT];
@@ -83,15 +85,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvArgs a) 
 #pragma unroll
     for (int i = 0; i < P_IT; ++i) {
       const char* p = p_src[i] ? reinterpret_cast<const char*>(p_src[i] + c0) : zero + slot * 16;
-      __builtin_amdgcn_global_load_lds((gl_void_t*)p, (lds_void_t*)(dst + (wave + 4 * i) * 1024), 16, 0, 0);
+      dma16(p, lds_addr(dst + (wave + 4 * i) * 1024));
     }
   };
   auto issue_b = [&](int stage, int tap, int c0) {
     unsigned char* dst = bring + stage * B_BYTES;
     const size_t off = (size_t)tap * a.Ci + c0;
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i)
-      __builtin_amdgcn_global_load_lds((gl_void_t*)(b_src[i] + off), (lds_void_t*)(dst + (wave + 4 * i) * 1024), 16, 0, 0);
+    for (int i = 0; i < B_IT; ++i) dma16(b_src[i] + off, lds_addr(dst + (wave + 4 * i) * 1024));
   };
 
   // ---- fragment geometry ------------------------------------------------------------------------
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvArgs a) 
 
 template <int BN, int TH, int TW>
 static int launch_halo(const ConvArgs& a, hipStream_t s) {
-  const int grid = a.N * (a.Hi / TH) * (a.Wi / TW) * (a.Co / BN);
+  const int grid = a.N * (a.Ho / TH) * (a.Wo / TW) * (a.Co / BN);
   constexpr int lds_bytes = HaloCfg<BN, TH, TW>::LDS_BYTES;
   static bool configured = false;        // immutable after the first call (set before any launch of this variant)
   if (!configured) {

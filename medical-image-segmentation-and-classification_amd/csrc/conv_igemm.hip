@@ -261,11 +261,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 // (the DMA writes lane-linear: lane (row, slot) fetches chunk slot ^ swz(row) of its pixel row);
 // padding / stride-hole rows read a 256-B zero page.
 // ==============================================================================================
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void gl_void_t;
-__device__ uint4 g_zero_page[16];
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+#include "dma.hpp"
 
 template <int BN, int BK, int NS>
 __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvArgs a) {
@@ -347,12 +343,11 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvArgs a) {
       tw >>= a.up;
       const char* p = ok ? reinterpret_cast<const char*>(in + ((size_t)(a_nb[i] + th) * a.Wi + tw) * a.ldi + c0 + a_ck[i])
                          : zero + slot * 16;
-      __builtin_amdgcn_global_load_lds((gl_void_t*)p, (lds_void_t*)(la + (wave + 4 * i) * 1024), 16, 0, 0);
+      dma16(p, lds_addr(la + (wave + 4 * i) * 1024));
     }
     const size_t boff = (size_t)(kh * a.KW + kw) * a.Ci + c0;
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i)
-      __builtin_amdgcn_global_load_lds((gl_void_t*)(b_ptr[i] + boff), (lds_void_t*)(lb + (wave + 4 * i) * 1024), 16, 0, 0);
+    for (int i = 0; i < B_IT; ++i) dma16(b_ptr[i] + boff, lds_addr(lb + (wave + 4 * i) * 1024));
   };
   auto swz = [](int row, int c) { return (c ^ ((row >> RPBS) & (CPR - 1))) << 4; };
 
@@ -518,11 +513,11 @@ extern "C" int mi355_conv2d_igemm(const void* in, const void* wk, const float* b
       return launch_bn<bf16_t, 32>(a, st);
     }
     // 3x3 stride-1 pad-1 forward / data gradient on tile-divisible images: halo-patch kernel
-    const bool is3x3s1 = KH == 3 && KW == 3 && mul == 1 && div == 1 && !up && Hi == Ho && Wi == Wo &&
-                         ((kmul == 1 && off == -1) || (kmul == -1 && off == 1));
-    if (variant == 6 && is3x3s1 && Co % 64 == 0) {   // experimental: measured slower than the DMA ring (barrier-bound)
-      if (Wi % 32 == 0 && Hi % 8 == 0) return Co % 128 == 0 ? launch_halo<128, 8, 32>(a, st) : launch_halo<64, 8, 32>(a, st);
-      if (Wi % 16 == 0 && Hi % 16 == 0) return Co % 128 == 0 ? launch_halo<128, 16, 16>(a, st) : launch_halo<64, 16, 16>(a, st);
+    const bool is3x3s1 = KH == 3 && KW == 3 && mul == 1 && div == 1 && Ho == a.Hlog && Wo == a.Wlog &&
+                         ((kmul == 1 && off == -1) || (kmul == -1 && off == 1 && !up));
+    if (variant == 1 && is3x3s1 && Co % 64 == 0) {
+      if (Wo % 32 == 0 && Ho % 8 == 0) return Co % 128 == 0 ? launch_halo<128, 8, 32>(a, st) : launch_halo<64, 8, 32>(a, st);
+      if (Wo % 16 == 0 && Ho % 16 == 0) return Co % 128 == 0 ? launch_halo<128, 16, 16>(a, st) : launch_halo<64, 16, 16>(a, st);
     }
     // measured on MI355X (AttentionUNet shapes): the 2-deep BK=64 ring (2 workgroups/CU) wins for 128-wide
     // tiles, the 3-deep BK=32 ring (3-4 workgroups/CU) for 64-wide tiles and for Ci % 64 != 0

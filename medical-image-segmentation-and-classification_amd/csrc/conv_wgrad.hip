@@ -10,6 +10,9 @@
 // gridDim.z; every split writes its own fp32 slab (deterministic), summed by
 // mi355_conv2d_wgrad_reduce into the parameter-gradient layout.
 #include "common.hpp"
+#include "dma.hpp"
+#include "wgrad3x3_halo.hpp"
+#include <stdlib.h>
 
 struct WgradArgs {
   const void* x;
@@ -209,7 +212,19 @@ static void wgrad_tiles(int Co, int Ci, int& bco, int& bci) {
   bci = (Ci % 128 == 0) ? 128 : 64;
 }
 
+static bool halo_wgrad_shape(int Ho, int Wo, int KH, int KW) { return KH == 3 && KW == 3 && Wo % 32 == 0 && Ho % 8 == 0; }
+
 extern "C" int mi355_conv2d_wgrad_splits(int N, int Ho, int Wo, int Ci, int Co, int KH, int KW) {
+  if (halo_wgrad_shape(Ho, Wo, KH, KW)) {      // nine-tap kernel: 64x64 tiles, work items = 32-pixel-wide row bands
+    const int rb = Ho % 32 == 0 ? 32 : (Ho % 16 == 0 ? 16 : 8);
+    const long long items = (long long)N * (Wo / 32) * (Ho / rb);
+    const long long tiles = (long long)ceil_div(Co, 64) * ceil_div(Ci, 64);
+    long long s = 1024 / tiles;
+    if (s > items) s = items;
+    const long long slab = (long long)Co * 9 * Ci * 4;
+    while (s > 1 && s * slab > (512ll << 20)) --s;
+    return (int)(s < 1 ? 1 : s);
+  }
   int bco, bci;
   wgrad_tiles(Co, Ci, bco, bci);
   const long long M = (long long)N * Ho * Wo;
@@ -261,6 +276,20 @@ extern "C" int mi355_conv2d_wgrad(const void* x, const void* dy, float* ws, int 
   a.Hlog = up ? 2 * Hi : Hi;
   a.Wlog = up ? 2 * Wi : Wi;
   a.chunk = ceil_div(ceil_div(a.M, splits), 32) * 32;
+  static const int use_halo = getenv("MI355_WGRAD_HALO") ? atoi(getenv("MI355_WGRAD_HALO")) : 1;
+  if (dtype == MI355_BF16 && use_halo && stride == 1 && pad == 1 && halo_wgrad_shape(Ho, Wo, KH, KW) && Ho == a.Hlog && Wo == a.Wlog) {
+    Wgrad3Args h;
+    h.x = x; h.dy = dy; h.ws = ws;
+    h.N = N; h.Hi = Hi; h.Wi = Wi; h.Ci = Ci; h.ldx = ldx;
+    h.H = Ho; h.W = Wo; h.Co = Co; h.ldy = ldy; h.up = up ? 1 : 0;
+    h.RB = Ho % 32 == 0 ? 32 : (Ho % 16 == 0 ? 16 : 8);
+    h.items = N * (Wo / 32) * (Ho / h.RB);
+    h.items_per_block = ceil_div(h.items, splits);
+    dim3 grid(ceil_div(Co, 64) * ceil_div(Ci, 64), splits);
+    hipLaunchKernelGGL(wgrad3x3_halo_kernel, grid, dim3(256), 0, (hipStream_t)s, h);
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+  }
   if (dtype == MI355_BF16) return wgrad_launch<bf16_t>(a, splits, (hipStream_t)s);
   if (dtype == MI355_F32) return wgrad_launch<float>(a, splits, (hipStream_t)s);
   MI355_FAIL(MI355_ERR_UNSUPPORTED, "conv2d_wgrad: unknown dtype %d", dtype);

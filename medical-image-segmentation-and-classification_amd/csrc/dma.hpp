@@ -1,0 +1,30 @@
+// LDS-DMA helpers shared by the MFMA kernels (gfx950).
+#pragma once
+#include "common.hpp"
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gl_void_t;
+static __device__ uint4 g_zero_page[16];   // 256 B of zeros: DMA source for padding rows (one copy per translation unit)
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+
+// One 1-KiB LDS-DMA piece: lane i's 16 bytes at `gsrc` land at LDS byte address lds_base + 16*i.
+// Issued from inline asm ON PURPOSE: hipcc's waitcnt pass then does not know an LDS write is pending
+// and does not drain vmcnt(0) in front of the next ds_read (which would serialise the whole ring);
+// ordering is ours: counted s_waitcnt vmcnt + s_barrier before a stage is read (cdna guide 5.7).
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_base)
+      : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) void*)p);
+}
+

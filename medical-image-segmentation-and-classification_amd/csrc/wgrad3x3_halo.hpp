@@ -1,0 +1,149 @@
+// Weight gradient of a 3x3 / stride-1 / pad-1 convolution, bf16, gfx950 — all nine taps per workgroup.
+//
+//   dW[co][tap][ci] = sum_{n,y,x} dY[n,y,x,co] * X[n, y+kh-1, x+kw-1, ci]
+//
+// A workgroup owns a 64(co) x 64(ci) tile of dW for ALL nine taps (wave w = 32x32 quadrant, nine
+// f32x16 accumulators) and walks 32-pixel row segments of the image: per step it needs ONE new dY
+// row segment and ONE new X row segment (a rolling 3-row window with a 1-pixel halo serves the nine
+// shifted reads), so dY and X are streamed from L2 once per 18 MFMAs per wave instead of once per 2
+// — 9x less L2->LDS traffic than the per-tap split-K kernel (which is L2-bound for C <= 128).
+// Rows arrive by LDS-DMA (asm-issued, counted vmcnt, 2 rows of prefetch distance); fragments are
+// fetched with the hardware transpose read ds_read_b64_tr_b16 from [pixel][64 ch] row images whose
+// 16-B chunks are XOR-swizzled by ((pixel >> 1) & 1) << 2 (conflict-free for any pixel shift).
+// (nearest x2 up-sampling of X is folded into the row gather.)
+#pragma once
+#include "common.hpp"
+
+struct Wgrad3Args {
+  const void* x;
+  const void* dy;
+  float* ws;
+  int N, Hi, Wi, Ci, ldx;        // physical X
+  int H, W, Co, ldy;             // dY / logical X grid
+  int up;
+  int RB;                        // rows per work item
+  int items, items_per_block;
+};
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+
+__global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args a) {
+  typedef bf16_t T;
+  constexpr int XPX = 40, XROW = XPX * 128, DROW = 32 * 128;      // row images in bytes
+  constexpr int NRX = 5, NRD = 4;
+  constexpr int X_BYTES = NRX * XROW, D_BYTES = NRD * DROW;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[X_BYTES + D_BYTES + 4096];
+  unsigned char* const xr = lds;
+  unsigned char* const dr = lds + X_BYTES;
+  unsigned char* const dump = lds + X_BYTES + D_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, r32 = lane & 31;
+  const int qo = wave >> 1, qi = wave & 1;
+  const int ciTiles = (a.Ci + 63) / 64;
+  const int co0 = (blockIdx.x / ciTiles) * 64, ci0 = (blockIdx.x % ciTiles) * 64;
+  const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
+  const T* __restrict__ dy = reinterpret_cast<const T*>(a.dy);
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+  // DMA lane geometry: a 1-KiB piece = 8 pixels x 128 B; lane -> (pixel, 16-B slot)
+  const int lpx = lane >> 3, slot = lane & 7;
+  const bool ci_ok = ci0 + 8 * slot < a.Ci || true;     // chunk validity is decided after un-swizzling below
+  (void)ci_ok;
+  const int TXN = a.W / 32, BANDS = a.H / a.RB;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // transpose-read lane geometry (see conv_wgrad.hip)
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+  const int colA = qo * 32 + 16 * tg + 4 * tp;      // channel inside the 64-wide dY row image
+  const int colB = qi * 32 + 16 * tg + 4 * tp;
+  auto rd = [&](const unsigned char* row_img, int px, int col) {
+    const int chunk = (col >> 3) ^ (((px >> 1) & 1) << 2);
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(row_img + px * 128 + chunk * 16 + (col & 7) * 2));
+  };
+
+  const int item0 = blockIdx.y * a.items_per_block;
+  const int item1 = min(a.items, item0 + a.items_per_block);
+  for (int item = item0; item < item1; ++item) {
+    int t = item;
+    const int band = t % BANDS; t /= BANDS;
+    const int tx = t % TXN;
+    const int n = t / TXN;
+    const int ya = band * a.RB, yb = ya + a.RB, x0 = tx * 32;
+
+    // L(r): dY row r piece `wave`, X row r piece `wave`, X row r piece 4 (wave 0) — 3 DMA per wave
+    auto issue_row = [&](int r) {
+      const int ds = ((r - ya) + NRD * 8) % NRD, xs = ((r - (ya - 1)) + NRX * 8) % NRX;
+      {   // dY piece: pixels 8*wave .. +7 of row r
+        const int px = 8 * wave + lpx;
+        const int chunk = slot ^ (((px >> 1) & 1) << 2);
+        const int c = co0 + 8 * chunk;
+        const bool ok = r >= ya && r < yb && c < a.Co;
+        const char* p = ok ? reinterpret_cast<const char*>(dy + ((size_t)(n * a.H + r) * a.W + x0 + px) * a.ldy + c) : zero + slot * 16;
+        dma16(p, lds_addr(dr + ds * DROW + wave * 1024));
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int piece = k == 0 ? wave : 4;
+        const bool real = k == 0 || wave == 0;
+        const int px = 8 * piece + lpx;              // pixel of the 40-px row image; image x = x0 - 4 + px
+        const int xx = x0 - 4 + px;
+        const int chunk = slot ^ (((px >> 1) & 1) << 2);
+        const int c = ci0 + 8 * chunk;
+        const bool ok = real && (unsigned)r < (unsigned)a.H && (unsigned)xx < (unsigned)a.W && c < a.Ci;
+        const char* p = ok ? reinterpret_cast<const char*>(x + ((size_t)(n * a.Hi + (r >> a.up)) * a.Wi + (xx >> a.up)) * a.ldx + c)
+                           : zero + slot * 16;
+        dma16(p, lds_addr(real ? xr + xs * XROW + piece * 1024 : dump + wave * 1024));
+      }
+    };
+
+    // prologue: rows ya-1 .. ya+2 in flight, first three landed
+    issue_row(ya - 1);
+    issue_row(ya);
+    issue_row(ya + 1);
+    issue_row(ya + 2);
+    wait_vmcnt<3>();
+    __builtin_amdgcn_s_barrier();
+
+    for (int y = ya; y < yb; ++y) {
+      const bool more = y + 3 <= yb;               // rows up to yb (the bottom halo) are ever needed
+      if (more) issue_row(y + 3);
+      const unsigned char* dimg = dr + (((y - ya) + NRD * 8) % NRD) * DROW;
+      const unsigned char* ximg[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) ximg[k] = xr + (((y + k - 1 - (ya - 1)) + NRX * 8) % NRX) * XROW;
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const int pbase = ss * 16 + 8 * h + tq;      // tile pixel of this lane's first transpose block
+        const s16x4 a0 = rd(dimg, pbase, colA), a1 = rd(dimg, pbase + 4, colA);
+        const bf16x8 af = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int px = pbase + 3 + kw;           // image x = x0 + pixel + kw - 1  <=>  row-image pixel + 3 + kw
+            const s16x4 b0 = rd(ximg[kh], px, colB), b1 = rd(ximg[kh], px + 4, colB);
+            const bf16x8 bf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[kh * 3 + kw], 0, 0, 0);
+          }
+      }
+      if (more) wait_vmcnt<3>(); else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+
+  float* __restrict__ ws = a.ws + (size_t)blockIdx.y * a.Co * 9 * a.Ci;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + qo * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int ci = ci0 + qi * 32 + r32;
+      if (co < a.Co && ci < a.Ci) ws[((size_t)co * 9 + t) * a.Ci + ci] = acc[t][r];
+    }
+}

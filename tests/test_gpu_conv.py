@@ -20,6 +20,12 @@ CASES = [  # N, Ci, H, W, Co, K, stride, pad, up
     (2, 64, 6, 6, 32, 3, 1, 1, 1),
     (2, 128, 10, 10, 256, 3, 1, 1, 0),
     (1, 96, 8, 8, 96, 3, 1, 1, 0),
+    # halo-patch kernel shapes: (W % 32, H % 8) and (W % 16, H % 16) tiles, fused up-sampling, Co = 64 / 128
+    (2, 64, 16, 32, 128, 3, 1, 1, 0),
+    (1, 32, 8, 64, 64, 3, 1, 1, 0),
+    (2, 96, 16, 16, 192, 3, 1, 1, 0),
+    (2, 64, 8, 16, 128, 3, 1, 1, 1),
+    (1, 128, 24, 32, 64, 3, 1, 1, 0),
 ]
 
 
@@ -123,6 +129,13 @@ WG_CASES = [  # N, Ci, H, W, Co, K, stride, pad, up
     (2, 128, 10, 10, 256, 3, 1, 1, 0),
     (4, 128, 24, 24, 128, 3, 1, 1, 0),
     (1, 96, 8, 8, 160, 3, 1, 1, 0),
+    # nine-tap halo kernel shapes (W % 32 == 0, H % 8 == 0), incl. channel tails and fused up-sampling
+    (2, 64, 16, 32, 64, 3, 1, 1, 0),
+    (1, 32, 8, 64, 96, 3, 1, 1, 0),
+    (2, 64, 8, 32, 32, 3, 1, 1, 0),
+    (2, 128, 8, 16, 64, 3, 1, 1, 1),
+    (1, 192, 40, 32, 128, 3, 1, 1, 0),
+    (3, 64, 32, 96, 64, 3, 1, 1, 0),
 ]
 
 

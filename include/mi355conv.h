@@ -111,18 +111,20 @@ int mi355_bn_act(const void* x, int ldx, const float* scale, const float* shift,
                  const void* res, int ldr, void* y, int ldy, long long M, int C, int act, int dtype,
                  mi355_stream_t s);
 /* Backward reductions for y = act(bn(x) [+ other]) given dL/dy:
- * partial sums of g and g*xhat per channel, g = dy * (y > 0 if act). */
+ * partial sums of g and g*xhat per channel, g = dy * (y > 0 if act).  When `y` is NULL the ReLU mask
+ * is recomputed as x*mscale[c]+mshift[c] > 0 (the forward's own coefficients), which saves reading
+ * the activated tensor; `y` is required when a residual / second operand was added before the ReLU. */
 int mi355_bn_bwd_reduce(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,
-                        const float* mean, const float* invstd, float* partial, long long M, int C,
-                        int act, int dtype, mi355_stream_t s);
+                        const float* mean, const float* invstd, const float* mscale, const float* mshift,
+                        float* partial, long long M, int C, int act, int dtype, mi355_stream_t s);
 /* sums[0..C) = sum g (dbeta), sums[C..2C) = sum g*xhat (dgamma); beta-accumulate into dgamma/dbeta. */
 int mi355_bn_bwd_finalize(const float* partial, int nblocks, int C, float* sums, float* dgamma, float* dbeta,
                           float acc, mi355_stream_t s);
 /* dx = gamma*invstd*(g - sum_g/M - xhat*sum_gx/M); optional dres = g (residual / second operand
  * gradient, pre-normalisation), optional bias-gradient partials (column sums of dx). */
 int mi355_bn_bwd_apply(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,
-                       const float* gamma, const float* mean, const float* invstd, const float* sums,
-                       void* dx, int lddx, void* dres, int lddres, float* dbias_partial,
+                       const float* gamma, const float* mean, const float* invstd, const float* mscale,
+                       const float* mshift, const float* sums, void* dx, int lddx, void* dres, int lddres, float* dbias_partial,
                        long long M, int C, int act, int dtype, mi355_stream_t s);
 /* out[c] (+)= sum_b partial[b*stride*C + c]  (used for conv bias gradients). */
 int mi355_colsum_finalize(const float* partial, int nblocks, int stride, int C, float* out, float acc,

@@ -185,36 +185,45 @@ template <typename T> struct BnBwdReduceOp {
   typedef float Acc;
   static constexpr int EPC = 16 / (int)sizeof(T);
   const T* dy; int lddy; const T* y; int ldy; const T* x; int ldx;
-  const float* mean; const float* invstd; int act;
-  float mu[EPC], is[EPC];
+  const float* mean; const float* invstd; const float* mscale; const float* mshift; int act;
+  float mu[EPC], is[EPC], ms[EPC], mt[EPC];
   __device__ void load_cols(int c0) {
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) { mu[e] = mean[c0 + e]; is[e] = invstd[c0 + e]; }
+    for (int e = 0; e < EPC; ++e) {
+      mu[e] = mean[c0 + e];
+      is[e] = invstd[c0 + e];
+      ms[e] = (act && !y) ? mscale[c0 + e] : 0.f;
+      mt[e] = (act && !y) ? mshift[c0 + e] : 0.f;
+    }
   }
   __device__ void apply(size_t row, int c0, Acc (&acc)[NQ][EPC]) const {
     const Vec16<T> g = ld16<T>(dy + row * lddy + c0);
     const Vec16<T> xv = ld16<T>(x + row * ldx + c0);
     Vec16<T> yv;
-    if (act) yv = ld16<T>(y + row * ldy + c0);
+    if (act && y) yv = ld16<T>(y + row * ldy + c0);
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
       float gg = to_f32<T>(g.v[e]);
-      if (act && !(to_f32<T>(yv.v[e]) > 0.f)) gg = 0.f;
+      const float xf = to_f32<T>(xv.v[e]);
+      if (act) {
+        const bool on = y ? (to_f32<T>(yv.v[e]) > 0.f) : (xf * ms[e] + mt[e] > 0.f);
+        if (!on) gg = 0.f;
+      }
       acc[0][e] += gg;
-      acc[1][e] += gg * (to_f32<T>(xv.v[e]) - mu[e]) * is[e];
+      acc[1][e] += gg * (xf - mu[e]) * is[e];
     }
   }
 };
 
 extern "C" int mi355_bn_bwd_reduce(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,
-                                   const float* mean, const float* invstd, float* partial, long long M, int C, int act,
-                                   int dtype, mi355_stream_t s) {
-  MI355_CHECK_ARG(dy && x && mean && invstd && partial && (!act || y), "bn_bwd_reduce: null pointer");
+                                   const float* mean, const float* invstd, const float* mscale, const float* mshift,
+                                   float* partial, long long M, int C, int act, int dtype, mi355_stream_t s) {
+  MI355_CHECK_ARG(dy && x && mean && invstd && partial && (!act || y || (mscale && mshift)), "bn_bwd_reduce: null pointer");
   if (dtype == MI355_BF16) {
-    BnBwdReduceOp<bf16_t> op{(const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, (const bf16_t*)x, ldx, mean, invstd, act};
+    BnBwdReduceOp<bf16_t> op{(const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, (const bf16_t*)x, ldx, mean, invstd, mscale, mshift, act};
     return rowred_launch<bf16_t>(op, M, C, partial, (hipStream_t)s);
   }
-  BnBwdReduceOp<float> op{(const float*)dy, lddy, (const float*)y, ldy, (const float*)x, ldx, mean, invstd, act};
+  BnBwdReduceOp<float> op{(const float*)dy, lddy, (const float*)y, ldy, (const float*)x, ldx, mean, invstd, mscale, mshift, act};
   return rowred_launch<float>(op, M, C, partial, (hipStream_t)s);
 }
 
@@ -245,13 +254,15 @@ template <typename T> struct BnBwdApplyOp {
   typedef float Acc;
   static constexpr int EPC = 16 / (int)sizeof(T);
   const T* dy; int lddy; const T* y; int ldy; const T* x; int ldx;
-  const float* gamma; const float* mean; const float* invstd; const float* sums;
+  const float* gamma; const float* mean; const float* invstd; const float* mscale; const float* mshift; const float* sums;
   T* dx; int lddx; T* dres; int lddres;
   float invM; int C; int act;
-  float mu[EPC], is[EPC], k0[EPC], k1[EPC], gi[EPC];
+  float mu[EPC], is[EPC], k0[EPC], k1[EPC], gi[EPC], ms[EPC], mt[EPC];
   __device__ void load_cols(int c0) {
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
+      ms[e] = (act && !y) ? mscale[c0 + e] : 0.f;
+      mt[e] = (act && !y) ? mshift[c0 + e] : 0.f;
       mu[e] = mean[c0 + e];
       is[e] = invstd[c0 + e];
       gi[e] = gamma[c0 + e] * is[e];
@@ -263,13 +274,17 @@ template <typename T> struct BnBwdApplyOp {
     const Vec16<T> g = ld16<T>(dy + row * lddy + c0);
     const Vec16<T> xv = ld16<T>(x + row * ldx + c0);
     Vec16<T> yv;
-    if (act) yv = ld16<T>(y + row * ldy + c0);
+    if (act && y) yv = ld16<T>(y + row * ldy + c0);
     Vec16<T> o, r;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
       float gg = to_f32<T>(g.v[e]);
-      if (act && !(to_f32<T>(yv.v[e]) > 0.f)) gg = 0.f;
-      const float xh = (to_f32<T>(xv.v[e]) - mu[e]) * is[e];
+      const float xf = to_f32<T>(xv.v[e]);
+      if (act) {
+        const bool on = y ? (to_f32<T>(yv.v[e]) > 0.f) : (xf * ms[e] + mt[e] > 0.f);
+        if (!on) gg = 0.f;
+      }
+      const float xh = (xf - mu[e]) * is[e];
       const float d = gi[e] * (gg - k0[e] - xh * k1[e]);
       o.v[e] = from_f32<T>(d);
       r.v[e] = from_f32<T>(gg);
@@ -281,17 +296,17 @@ template <typename T> struct BnBwdApplyOp {
 };
 
 extern "C" int mi355_bn_bwd_apply(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,
-                                  const float* gamma, const float* mean, const float* invstd, const float* sums, void* dx,
-                                  int lddx, void* dres, int lddres, float* dbias_partial, long long M, int C, int act,
-                                  int dtype, mi355_stream_t s) {
-  MI355_CHECK_ARG(dy && x && gamma && mean && invstd && sums && dx && (!act || y), "bn_bwd_apply: null pointer");
+                                  const float* gamma, const float* mean, const float* invstd, const float* mscale,
+                                  const float* mshift, const float* sums, void* dx, int lddx, void* dres, int lddres,
+                                  float* dbias_partial, long long M, int C, int act, int dtype, mi355_stream_t s) {
+  MI355_CHECK_ARG(dy && x && gamma && mean && invstd && sums && dx && (!act || y || (mscale && mshift)), "bn_bwd_apply: null pointer");
   const float invM = (float)(1.0 / (double)M);
   if (dtype == MI355_BF16) {
     BnBwdApplyOp<bf16_t> op{(const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, (const bf16_t*)x, ldx, gamma, mean, invstd,
-                            sums, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, invM, C, act};
+                            mscale, mshift, sums, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, invM, C, act};
     return rowred_launch<bf16_t>(op, M, C, dbias_partial, (hipStream_t)s);
   }
-  BnBwdApplyOp<float> op{(const float*)dy, lddy, (const float*)y, ldy, (const float*)x, ldx, gamma, mean, invstd, sums,
+  BnBwdApplyOp<float> op{(const float*)dy, lddy, (const float*)y, ldy, (const float*)x, ldx, gamma, mean, invstd, mscale, mshift, sums,
                          (float*)dx, lddx, (float*)dres, lddres, invM, C, act};
   return rowred_launch<float>(op, M, C, dbias_partial, (hipStream_t)s);
 }

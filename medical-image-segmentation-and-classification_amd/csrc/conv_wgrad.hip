@@ -219,7 +219,7 @@ extern "C" int mi355_conv2d_wgrad_splits(int N, int Ho, int Wo, int Ci, int Co, 
     const int rb = Ho % 32 == 0 ? 32 : (Ho % 16 == 0 ? 16 : 8);
     const long long items = (long long)N * (Wo / 32) * (Ho / rb);
     const long long tiles = (long long)ceil_div(Co, 64) * ceil_div(Ci, 64);
-    long long s = 1024 / tiles;
+    long long s = 512 / tiles;                 // 2 workgroups per CU are resident (216 VGPRs): one full wave of blocks
     if (s > items) s = items;
     const long long slab = (long long)Co * 9 * Ci * 4;
     while (s > 1 && s * slab > (512ll << 20)) --s;
@@ -296,15 +296,14 @@ extern "C" int mi355_conv2d_wgrad(const void* x, const void* dy, float* ws, int 
 }
 
 // dw[co][ci][kh][kw] (or [ci][co][kh][kw] when transposed) = beta*dw + sum_s ws[s][co][tap][ci]
-// One workgroup per (co, 32-channel ci tile).  Thread (kl, cl) sums splits kl, kl+8, ... of channel
-// ci0+cl for every tap (slab reads are 128-B ci-contiguous runs, 8 split lanes keep loads in flight),
-// the 8 split lanes are folded through LDS, and the result is written transposed so that the
+// One 1024-thread workgroup per (co, 32-channel ci tile).  Thread (kl, cl) sums splits kl, kl+32, ... of channel
+// ci0+cl for every tap (slab reads are 128-B ci-contiguous runs, 32 split lanes keep loads in flight),
+// the 32 split lanes are folded through LDS, and the result is written transposed so that the
 // parameter-gradient stores are contiguous runs of 32*taps floats.
 #define WR_CI 32
-#define WR_KL 8
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, float* __restrict__ dw, int Co,
-                                                           int Ci, int Ci_real, int taps, int transposed, float beta) {
-  extern __shared__ float tile[];                 // [WR_KL][taps][WR_CI + 1]
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, float* __restrict__ dw, int Co,
+                                                            int Ci, int Ci_real, int taps, int transposed, float beta, int KL) {
+  extern __shared__ float tile[];                 // [KL][taps][WR_CI + 1]
   const int ciTiles = (Ci + WR_CI - 1) / WR_CI;
   const int co = blockIdx.x / ciTiles, ci0 = (blockIdx.x % ciTiles) * WR_CI;
   const size_t total = (size_t)Co * taps * Ci;
@@ -316,9 +315,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (ci < Ci) {
       const float* p = ws + ((size_t)co * taps + tap) * Ci + ci;
       int k = kl;
-      for (; k + WR_KL < splits; k += 2 * WR_KL) {
+      for (; k + KL < splits; k += 2 * KL) {
         s0 += p[(size_t)k * total];
-        s1 += p[(size_t)(k + WR_KL) * total];
+        s1 += p[(size_t)(k + KL) * total];
       }
       if (k < splits) s0 += p[(size_t)k * total];
     }
@@ -326,13 +325,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
   __syncthreads();
   const int n = taps * WR_CI;
-  for (int t = threadIdx.x; t < n; t += 256) {
+  for (int t = threadIdx.x; t < n; t += WR_CI * KL) {
     const int c2 = t / taps, tap = t - c2 * taps;
     const int cc = ci0 + c2;
     if (cc >= Ci_real) continue;
     float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < WR_KL; ++k) s += tile[k * tstride + tap * (WR_CI + 1) + c2];
+    for (int k = 0; k < KL; ++k) s += tile[k * tstride + tap * (WR_CI + 1) + c2];
     const size_t o = transposed ? ((size_t)cc * Co + co) * taps + tap : ((size_t)co * Ci_real + cc) * taps + tap;
     dw[o] = (beta != 0.f ? beta * dw[o] : 0.f) + s;
   }
@@ -343,8 +341,12 @@ extern "C" int mi355_conv2d_wgrad_reduce(const float* ws, int splits, float* dw,
   MI355_CHECK_ARG(ws && dw && splits >= 1, "conv2d_wgrad_reduce: bad arguments");
   const int taps = KH * KW;
   const int ciTiles = (Ci + WR_CI - 1) / WR_CI;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(Co * ciTiles), dim3(256), WR_KL * taps * (WR_CI + 1) * sizeof(float), (hipStream_t)s,
-                     ws, splits, dw, Co, Ci, Ci_real, taps, transposed, beta);
+  int KL = 15000 / (taps * (WR_CI + 1));          // split lanes per channel: as many as fit 60 KB of LDS, at most 32
+  if (KL > 32) KL = 32;
+  if (KL > splits) KL = splits;
+  if (KL < 1) KL = 1;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(Co * ciTiles), dim3(WR_CI * KL), KL * taps * (WR_CI + 1) * sizeof(float), (hipStream_t)s,
+                     ws, splits, dw, Co, Ci, Ci_real, taps, transposed, beta, KL);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }

@@ -365,7 +365,8 @@ class Builder:
         assert (y.N, y.H, y.W, y.C) == (x.N, Ho, Wo, Co)
         flops = 2 * x.N * Ho * Wo * Co * k * k * conv.in_channels
         self.fwd.append(Launch("mi355_conv2d_igemm", x, wf, conv.bias, y, x.N, x.H, x.W, x.C, x.ld, Ho, Wo, Co, y.ld,
-                               k, k, s, 1, -p, 1, 1 if up else 0, 0, self.code, flops=flops, tag=self.igemm_tag(Co, x.C)))
+                               k, k, s, 1, -p, 1, 1 if up else 0, 0, self.code, flops=flops,
+                               tag=self.igemm_tag(Co, x.C, k, s, Ho, Wo, False, up)))
         y.needs_grad = x.needs_grad or conv.weight.requires_grad
 
         def bwd(dy, bias_done=False):
@@ -373,7 +374,7 @@ class Builder:
                 splits = lib.mi355_conv2d_wgrad_splits(x.N, Ho, Wo, x.C, Co, k, k)
                 ws = self.ws_bytes(splits * Co * k * k * x.C * 4)
                 self.bwd.append(Launch("mi355_conv2d_wgrad", x, dy, ws, splits, x.N, x.H, x.W, x.C, x.ld, Ho, Wo, Co, dy.ld,
-                                       k, k, s, p, 1 if up else 0, self.code, flops=flops, tag=self.wgrad_tag(Co, x.C)))
+                                       k, k, s, p, 1 if up else 0, self.code, flops=flops, tag=self.wgrad_tag(Co, x.C, k, s, Ho, Wo)))
                 ref, beta = self.pgrad(conv.weight)
                 self.bwd.append(Launch("mi355_conv2d_wgrad_reduce", ws, splits, ref, Co, x.C, conv.in_channels, k, k, 0, beta))
             if conv.bias is not None and conv.bias.requires_grad and not bias_done:
@@ -382,7 +383,8 @@ class Builder:
                 if up:
                     tmp = self.new_tensor(x.N, 2 * x.H, 2 * x.W, x.C)
                     self.bwd.append(Launch("mi355_conv2d_igemm", dy, wb, None, tmp, x.N, Ho, Wo, Co, dy.ld, 2 * x.H, 2 * x.W,
-                                           x.C, tmp.ld, k, k, 1, -1, p, s, 0, 0, self.code, flops=flops, tag=self.igemm_tag(x.C, Co)))
+                                           x.C, tmp.ld, k, k, 1, -1, p, s, 0, 0, self.code, flops=flops,
+                                           tag=self.igemm_tag(x.C, Co, k, s, 2 * x.H, 2 * x.W, True, False)))
                     acc = self.acc_flag(x)
                     xg = self.grad_of(x)
                     self.bwd.append(Launch("mi355_upsample2_bwd", tmp, tmp.ld, xg, xg.ld, x.N, x.H, x.W, x.C, acc, self.code))
@@ -390,18 +392,31 @@ class Builder:
                     acc = self.acc_flag(x)
                     xg = self.grad_of(x)
                     self.bwd.append(Launch("mi355_conv2d_igemm", dy, wb, None, xg, x.N, Ho, Wo, Co, dy.ld, x.H, x.W, x.C,
-                                           xg.ld, k, k, 1, -1, p, s, 0, acc, self.code, flops=flops, tag=self.igemm_tag(x.C, Co)))
+                                           xg.ld, k, k, 1, -1, p, s, 0, acc, self.code, flops=flops,
+                                           tag=self.igemm_tag(x.C, Co, k, s, x.H, x.W, True, False)))
         return y, bwd
 
-    def igemm_tag(self, co, ci):
-        """Kernel variant mi355_conv2d_igemm dispatches to (mirrors csrc/conv_igemm.hip)."""
+    def igemm_tag(self, co, ci, k=1, s=1, Ho=0, Wo=0, dgrad=False, up=False):
+        """Kernel variant mi355_conv2d_igemm dispatches to (mirrors the launcher in csrc/conv_igemm.hip)."""
         bn = 128 if co % 128 == 0 else (64 if co % 64 == 0 else 32)
-        if self.dtype == torch.bfloat16:
-            return f"conv_igemm_kernel<bf16,{bn},{64 if ci % 64 == 0 else 32}>"
-        return f"conv_igemm_kernel<f32,{bn},16>"
+        if self.dtype != torch.bfloat16:
+            return f"conv_igemm_kernel<f32,{bn},16>"
+        if k == 3 and s == 1 and co % 64 == 0 and not (dgrad and up):
+            if Wo % 32 == 0 and Ho % 8 == 0:
+                return f"conv3x3_halo_kernel<{min(bn, 128)},8,32>"
+            if Wo % 16 == 0 and Ho % 16 == 0:
+                return f"conv3x3_halo_kernel<{min(bn, 128)},16,16>"
+        k64 = ci % 64 == 0
+        if bn == 128:
+            return "conv_igemm_dma_kernel<128,64,2>" if k64 else "conv_igemm_dma_kernel<128,32,3>"
+        if bn == 64:
+            return "conv_igemm_dma_kernel<64,32,3>"
+        return "conv_igemm_dma_kernel<32,64,3>" if k64 else "conv_igemm_kernel<bf16,32,32>"
 
-    def wgrad_tag(self, co, ci):
+    def wgrad_tag(self, co, ci, k=1, s=1, Ho=0, Wo=0):
         t = "bf16" if self.dtype == torch.bfloat16 else "f32"
+        if t == "bf16" and k == 3 and s == 1 and Wo % 32 == 0 and Ho % 8 == 0:
+            return "wgrad3x3_halo_kernel"
         return f"conv_wgrad_kernel<{t},{128 if co % 128 == 0 else 64},{128 if ci % 128 == 0 else 64}>"
 
     def bias_grad_from(self, dy, bias):
@@ -437,8 +452,11 @@ class Builder:
         C = bn.num_features
         nb = lib.mi355_rowreduce_blocks(y.M)
         part = self.ws_f32(nb * 2 * C)
-        self.bwd.append(Launch("mi355_bn_bwd_reduce", da, da.ld, a if act else None, a.ld if act else 0, y, y.ld,
-                               st["mean"], st["invstd"], part, y.M, C, 1 if act else 0, self.code))
+        # the ReLU mask is recomputed from the raw input with the forward's coefficients unless something was
+        # added in front of the ReLU (residual / second operand), in which case the activated tensor is read
+        am = a if (act and dres_to is not None) else None
+        self.bwd.append(Launch("mi355_bn_bwd_reduce", da, da.ld, am, am.ld if am is not None else 0, y, y.ld,
+                               st["mean"], st["invstd"], st["scale"], st["shift"], part, y.M, C, 1 if act else 0, self.code))
         sums = self.f32(2 * C)
         need_pg = bn.weight.requires_grad
         if need_pg:
@@ -455,8 +473,8 @@ class Builder:
                 dres = self.grad_of(dres_to)
         want_bias = bias is not None and bias.requires_grad
         part1 = self.ws_f32(nb * 2 * C + nb * C) if want_bias else None
-        self.bwd.append(Launch("mi355_bn_bwd_apply", da, da.ld, a if act else None, a.ld if act else 0, y, y.ld, bn.weight,
-                               st["mean"], st["invstd"], sums, dy, dy.ld, dres, dres.ld if dres is not None else 0,
+        self.bwd.append(Launch("mi355_bn_bwd_apply", da, da.ld, am, am.ld if am is not None else 0, y, y.ld, bn.weight,
+                               st["mean"], st["invstd"], st["scale"], st["shift"], sums, dy, dy.ld, dres, dres.ld if dres is not None else 0,
                                (self._ws_off(part1, nb * 2 * C * 4) if want_bias else None), y.M, C, 1 if act else 0, self.code))
         if want_bias:
             ref, beta = self.pgrad(bias)

@@ -69,12 +69,13 @@ def test_bn_backward(dtype, act, with_res):
     mu = x.detach().mean((0, 2, 3)); isd = 1 / torch.sqrt(x.detach().var((0, 2, 3), unbiased=False) + 1e-5)
     nb, part = _partials(m, c)
     code = DTYPE_CODE[dtype]
-    lib.mi355_bn_bwd_reduce(dyd, c, yd, c, xd, c, dev(mu), dev(isd), part, m, c, act, code)
+    lib.mi355_bn_bwd_reduce(dyd, c, yd if with_res else None, c, xd, c, dev(mu), dev(isd), dev(gamma.detach() * isd), dev(beta.detach() - mu * gamma.detach() * isd), part, m, c, act, code)
     sums = torch.empty(2 * c, device=DEV); dgam = torch.ones(c, device=DEV); dbet = torch.ones(c, device=DEV)
     lib.mi355_bn_bwd_finalize(part, nb, c, sums, dgam, dbet, 1.0)      # accumulate onto ones
     dx = torch.empty_like(xd); dres = torch.empty_like(xd)
     nb1, p1 = _partials(m, c, 1)
-    lib.mi355_bn_bwd_apply(dyd, c, yd, c, xd, c, dev(gamma.detach()), dev(mu), dev(isd), sums, dx, c,
+    lib.mi355_bn_bwd_apply(dyd, c, yd if with_res else None, c, xd, c, dev(gamma.detach()), dev(mu), dev(isd),
+                           dev(gamma.detach() * isd), dev(beta.detach() - mu * gamma.detach() * isd), sums, dx, c,
                            dres if with_res else None, c, p1, m, c, act, code)
     dbias = torch.empty(c, device=DEV)
     lib.mi355_colsum_finalize(p1, nb1, 1, c, dbias, 0.0)

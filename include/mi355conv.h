@@ -67,12 +67,20 @@ int mi355_pack_conv_weight(const float* w, void* wf, void* wb, int Co, int Ci, i
  *   input grad, reached from loss.backward(), utils/helpers.py:329)
  * ConvTranspose2d(k,s)        : data-gradient form with wk = Wf of the transposed parameter
  *   (ResnetUnet.py:21,51).
- * Ci % 32 == 0 (16 for fp32), Co % 32 == 0.  accumulate != 0 adds into `out`. */
+ * Ci % 32 == 0 (16 for fp32), Co % 32 == 0.  accumulate != 0 adds into `out`.
+ * bf16 dispatch: 3x3/s1 on tile-divisible images -> conv3x3_halo_kernel (halo patch in LDS, LDS-DMA),
+ * everything else -> conv_igemm_dma_kernel (LDS-DMA ring); fp32 -> register-staged conv_igemm_kernel. */
 int mi355_conv2d_igemm(const void* in, const void* wk, const float* bias, void* out,
                        int N, int Hi, int Wi, int Ci, int ldi,
                        int Ho, int Wo, int Co, int ldo,
                        int KH, int KW, int mul, int kmul, int off, int div, int up,
-                       int accumulate, int dtype, mi355_stream_t s);
+                       int accumulate, float* stats, int dtype, mi355_stream_t s);
+/* Fused BatchNorm statistics: when `stats` != NULL the epilogue also writes, per M tile b of the kernel
+ * it dispatches to, stats[(b*2+0)*Co + c] = sum and stats[(b*2+1)*Co + c] = sum of squares of the
+ * (rounded) outputs — the same partial layout mi355_bn_finalize consumes.  The number of tile rows is
+ * mi355_conv2d_igemm_stat_rows(...) (0 = not available for this shape/dtype: use mi355_bn_stats). */
+int mi355_conv2d_igemm_stat_rows(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW,
+                                 int mul, int kmul, int off, int div, int up, int dtype);
 
 /* Weight gradient: ws[split][Co][KH*KW][Ci] = sum over the split's pixel range of
  * dy[m][co] * x[src(m,kh,kw)][ci] (forward addressing as above), then

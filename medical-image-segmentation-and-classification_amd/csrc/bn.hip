@@ -24,35 +24,37 @@ template <typename T> struct BnStatsOp {
 
 
 // ---- folding per-workgroup partials -----------------------------------------------------------------
-// Finalize kernels run one 1024-thread workgroup per 32 channels: thread (bl, cl) sums partial rows
-// b = bl, bl+32, ... for channel c0+cl (a wave reads four 128-B channel runs per step), then the 8
-// row-lanes are folded through LDS.  `q` selects the quantity, `nq` the quantities per block row.
-#define FIN_CH 32
-#define FIN_BL 32
+// Finalize kernels run 1024-thread workgroups of CH channels x BL row lanes: thread (bl, cl) sums partial
+// rows b = bl, bl+BL, ... for channel c0+cl, then the row lanes are folded through LDS.  <32,32> for the
+// row-reduce partials (<= 1024 rows); <4,256> when a conv epilogue produced one row per M tile (thousands).
+template <int CH, int BL>
 __device__ __forceinline__ double fold_partials(const float* __restrict__ partial, int nblocks, int rowlen, int off, int C,
                                                 double* red) {
-  const int cl = threadIdx.x % FIN_CH, bl = threadIdx.x / FIN_CH;
-  const int c = blockIdx.x * FIN_CH + cl;
+  const int cl = threadIdx.x % CH, bl = threadIdx.x / CH;
+  const int c = blockIdx.x * CH + cl;
   double s = 0;
   if (c < C) {
     double s1 = 0, s2 = 0, s3 = 0;
     int b = bl;
-    for (; b + 3 * FIN_BL < nblocks; b += 4 * FIN_BL) {      // four independent loads in flight
+    for (; b + 3 * BL < nblocks; b += 4 * BL) {      // four independent loads in flight
       s += (double)partial[(size_t)b * rowlen + off + c];
-      s1 += (double)partial[(size_t)(b + FIN_BL) * rowlen + off + c];
-      s2 += (double)partial[(size_t)(b + 2 * FIN_BL) * rowlen + off + c];
-      s3 += (double)partial[(size_t)(b + 3 * FIN_BL) * rowlen + off + c];
+      s1 += (double)partial[(size_t)(b + BL) * rowlen + off + c];
+      s2 += (double)partial[(size_t)(b + 2 * BL) * rowlen + off + c];
+      s3 += (double)partial[(size_t)(b + 3 * BL) * rowlen + off + c];
     }
-    for (; b < nblocks; b += FIN_BL) s += (double)partial[(size_t)b * rowlen + off + c];
+    for (; b < nblocks; b += BL) s += (double)partial[(size_t)b * rowlen + off + c];
     s += s1 + s2 + s3;
   }
-  red[bl * FIN_CH + cl] = s;
+  red[bl * CH + cl] = s;
   __syncthreads();
-  double t = 0;
-  if (bl == 0)
-    for (int k = 0; k < FIN_BL; ++k) t += red[k * FIN_CH + cl];
+  // log-step fold over the BL row lanes (every thread participates; result in row lane 0)
+  for (int st = BL / 2; st > 0; st >>= 1) {
+    if (bl < st) red[bl * CH + cl] += red[(bl + st) * CH + cl];
+    __syncthreads();
+  }
+  const double t = red[cl];
   __syncthreads();
-  return t;     // valid for threads with bl == 0
+  return t;     // valid for threads with bl == 0 (all threads read the same value)
 }
 
 extern "C" int mi355_rowreduce_blocks(long long M) { return rowreduce_blocks(M); }
@@ -67,16 +69,17 @@ extern "C" int mi355_bn_stats(const void* x, float* partial, long long M, int C,
   return rowred_launch<float>(op, M, C, partial, (hipStream_t)s);
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nblocks, double M, int C,
+template <int CH, int BL>
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partial, int nblocks, double M, int C,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ rmean, float* __restrict__ rvar, int64_t* nbt, float momentum,
                                    float eps, float* __restrict__ scale, float* __restrict__ shift,
                                    float* __restrict__ mean_out, float* __restrict__ invstd_out) {
-  __shared__ double red[FIN_CH * FIN_BL];
-  const double s = fold_partials(partial, nblocks, 2 * C, 0, C, red);
-  const double q = fold_partials(partial, nblocks, 2 * C, C, C, red);
-  const int c = blockIdx.x * FIN_CH + threadIdx.x;
-  if (threadIdx.x >= FIN_CH) return;
+  __shared__ double red[CH * BL];
+  const double s = fold_partials<CH, BL>(partial, nblocks, 2 * C, 0, C, red);
+  const double q = fold_partials<CH, BL>(partial, nblocks, 2 * C, C, C, red);
+  const int c = blockIdx.x * CH + threadIdx.x;
+  if (threadIdx.x >= CH) return;
   if (c == 0 && nbt) *nbt += 1;
   if (c >= C) return;
   const double mean = s / M;
@@ -100,8 +103,12 @@ extern "C" int mi355_bn_finalize(const float* partial, int nblocks, long long M,
                                  float momentum, float eps, float* scale, float* shift, float* mean, float* invstd,
                                  mi355_stream_t s) {
   MI355_CHECK_ARG(partial && gamma && beta && scale && shift && mean && invstd, "bn_finalize: null pointer");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, FIN_CH)), dim3(FIN_CH * FIN_BL), 0, (hipStream_t)s, partial, nblocks, (double)M, C,
-                     gamma, beta, running_mean, running_var, nbt, momentum, eps, scale, shift, mean, invstd);
+  if (nblocks > 2048)
+    hipLaunchKernelGGL((bn_finalize_kernel<4, 256>), dim3(ceil_div(C, 4)), dim3(1024), 0, (hipStream_t)s, partial, nblocks, (double)M, C,
+                       gamma, beta, running_mean, running_var, nbt, momentum, eps, scale, shift, mean, invstd);
+  else
+    hipLaunchKernelGGL((bn_finalize_kernel<32, 32>), dim3(ceil_div(C, 32)), dim3(1024), 0, (hipStream_t)s, partial, nblocks, (double)M, C,
+                       gamma, beta, running_mean, running_var, nbt, momentum, eps, scale, shift, mean, invstd);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }
@@ -229,11 +236,11 @@ extern "C" int mi355_bn_bwd_reduce(const void* dy, int lddy, const void* y, int 
 
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, float* __restrict__ sums,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta, float accf) {
-  __shared__ double red[FIN_CH * FIN_BL];
-  const double s0 = fold_partials(partial, nblocks, 2 * C, 0, C, red);
-  const double s1 = fold_partials(partial, nblocks, 2 * C, C, C, red);
-  const int c = blockIdx.x * FIN_CH + threadIdx.x;
-  if (threadIdx.x >= FIN_CH || c >= C) return;
+  __shared__ double red[32 * 32];
+  const double s0 = fold_partials<32, 32>(partial, nblocks, 2 * C, 0, C, red);
+  const double s1 = fold_partials<32, 32>(partial, nblocks, 2 * C, C, C, red);
+  const int c = blockIdx.x * 32 + threadIdx.x;
+  if (threadIdx.x >= 32 || c >= C) return;
   sums[c] = (float)s0;
   sums[C + c] = (float)s1;
   if (dbeta) dbeta[c] = (accf != 0.f ? accf * dbeta[c] : 0.f) + (float)s0;
@@ -243,7 +250,7 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nb
 extern "C" int mi355_bn_bwd_finalize(const float* partial, int nblocks, int C, float* sums, float* dgamma, float* dbeta,
                                      float acc, mi355_stream_t s) {
   MI355_CHECK_ARG(partial && sums, "bn_bwd_finalize: null pointer");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, FIN_CH)), dim3(FIN_CH * FIN_BL), 0, (hipStream_t)s, partial, nblocks, C, sums,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, (hipStream_t)s, partial, nblocks, C, sums,
                      dgamma, dbeta, acc);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
@@ -337,17 +344,17 @@ extern "C" int mi355_colsum(const void* x, int ld, float* partial, long long M, 
 
 __global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nblocks, int stride, int C,
                                        float* __restrict__ out, float accf) {
-  __shared__ double red[FIN_CH * FIN_BL];
-  const double s0 = fold_partials(partial, nblocks, stride * C, 0, C, red);
-  const int c = blockIdx.x * FIN_CH + threadIdx.x;
-  if (threadIdx.x >= FIN_CH || c >= C) return;
+  __shared__ double red[32 * 32];
+  const double s0 = fold_partials<32, 32>(partial, nblocks, stride * C, 0, C, red);
+  const int c = blockIdx.x * 32 + threadIdx.x;
+  if (threadIdx.x >= 32 || c >= C) return;
   out[c] = (accf != 0.f ? accf * out[c] : 0.f) + (float)s0;
 }
 
 extern "C" int mi355_colsum_finalize(const float* partial, int nblocks, int stride, int C, float* out, float acc,
                                      mi355_stream_t s) {
   MI355_CHECK_ARG(partial && out, "colsum_finalize: null pointer");
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(C, FIN_CH)), dim3(FIN_CH * FIN_BL), 0, (hipStream_t)s, partial, nblocks, stride, C,
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, (hipStream_t)s, partial, nblocks, stride, C,
                      out, acc);
   MI355_LAUNCH_CHECK();
   return MI355_OK;

@@ -20,7 +20,8 @@ template <int BN, int TH, int TW> struct HaloCfg {
   static constexpr int PATCH_BYTES = P_IT * 4 * 1024;
   static constexpr int RING = 2 * PATCH_BYTES + 3 * BN * 64;
   static constexpr int C_BYTES = TH * TW * (BN * 2 + 16);
-  static constexpr int LDS_BYTES = RING > C_BYTES ? RING : C_BYTES;
+  static constexpr int EPI_BYTES = C_BYTES + 4 * 2 * BN * 4;     // C tile + statistics scratch [WM<=4][2][BN]
+  static constexpr int LDS_BYTES = RING > EPI_BYTES ? RING : EPI_BYTES;
 };
 
 template <int BN, int TH, int TW>
@@ -187,6 +188,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvArgs a) 
   float bcol[NI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) bcol[ni] = a.bias ? a.bias[n0 + brow[ni]] : 0.f;
+  float* const red = reinterpret_cast<float*>(lds + HaloCfg<BN, TH, TW>::C_BYTES);      // [WM][2][BN] behind the C tile
+  if (a.stats) {        // fused BatchNorm statistics of the ROUNDED outputs this tile stores
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      float sm = 0.f, sq = 0.f;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = to_f32<T>(from_f32<T>(acc[mi][ni][r] + bcol[ni]));
+          sm += v;
+          sq += v * v;
+        }
+      sm += __shfl_xor(sm, 32, 64);
+      sq += __shfl_xor(sq, 32, 64);
+      if (h == 0) {
+        red[(wm * 2 + 0) * BN + brow[ni]] = sm;
+        red[(wm * 2 + 1) * BN + brow[ni]] = sq;
+      }
+    }
+  }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -197,6 +219,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvArgs a) 
         *reinterpret_cast<T*>(lds + row * C_PITCH + brow[ni] * 2) = from_f32<T>(acc[mi][ni][r] + bcol[ni]);
       }
   __syncthreads();
+  if (a.stats && tid < 2 * BN) {
+    const int q = tid / BN, c = tid - q * BN;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < WM; ++w) v += red[(w * 2 + q) * BN + c];
+    a.stats[((size_t)(blockIdx.x / NT) * 2 + q) * a.Co + n0 + c] = v;
+  }
   constexpr int CPRC = BN / EPC;
   for (int id = tid; id < BM * CPRC; id += 256) {
     const int row = id / CPRC, c = id - row * CPRC;

@@ -23,6 +23,7 @@ struct ConvArgs {
   int KH, KW;
   int mul, kmul, off, dshift, up;
   int accumulate;
+  float* stats;  // optional fused BatchNorm statistics: partial[(mblock*2+q)*Co + c], q = sum / sum of squares
   int M;        // N*Ho*Wo
   int HoWo;
   int Hlog, Wlog;   // logical (post-upsample) input extent
@@ -282,7 +283,8 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvArgs a) {
   constexpr int A_BYTES = BM * P, B_BYTES = BN * P, STAGE = A_BYTES + B_BYTES;
   constexpr int C_PITCH = BN * 2 + 16;
   constexpr int C_BYTES = BM * C_PITCH;
-  constexpr int LDS_BYTES = (NS * STAGE > C_BYTES) ? NS * STAGE : C_BYTES;
+  constexpr int EPI_BYTES = C_BYTES + WM * 2 * BN * 4;
+  constexpr int LDS_BYTES = (NS * STAGE > EPI_BYTES) ? NS * STAGE : EPI_BYTES;
   constexpr int PER_TILE = A_IT + B_IT;       // DMA instructions per wave per K tile
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
@@ -425,6 +427,29 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvArgs a) {
   float bcol[NI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) bcol[ni] = a.bias ? a.bias[n0 + wn * WTN + ni * 32 + r32] : 0.f;
+  float* const red = reinterpret_cast<float*>(lds + C_BYTES);      // [WM][2][BN] behind the C tile
+  static_assert(LDS_BYTES >= C_BYTES + WM * 2 * BN * 4, "no room for the statistics scratch");
+  if (a.stats) {        // fused BatchNorm statistics of the ROUNDED outputs this tile stores
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      float sm = 0.f, sq = 0.f;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float v = (m0 + row < a.M) ? to_f32<T>(from_f32<T>(acc[mi][ni][r] + bcol[ni])) : 0.f;
+          sm += v;
+          sq += v * v;
+        }
+      sm += __shfl_xor(sm, 32, 64);
+      sq += __shfl_xor(sq, 32, 64);
+      if (h == 0) {
+        red[(wm * 2 + 0) * BN + wn * WTN + ni * 32 + r32] = sm;
+        red[(wm * 2 + 1) * BN + wn * WTN + ni * 32 + r32] = sq;
+      }
+    }
+  }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -436,6 +461,13 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvArgs a) {
         *reinterpret_cast<T*>(lds + row * C_PITCH + col * 2) = from_f32<T>(acc[mi][ni][r] + bcol[ni]);
       }
   __syncthreads();
+  if (a.stats && tid < 2 * BN) {
+    const int q = tid / BN, c = tid - q * BN;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < WM; ++w) v += red[(w * 2 + q) * BN + c];
+    a.stats[((size_t)mt * 2 + q) * a.Co + n0 + c] = v;
+  }
   constexpr int CPRC = BN / EPC;
   for (int id = tid; id < BM * CPRC; id += 256) {
     const int row = id / CPRC, c = id - row * CPRC;
@@ -478,9 +510,39 @@ static int launch_bn(const ConvArgs& a, hipStream_t s) {
   return launch<T, 32, BK>(a, s);
 }
 
+enum IgemmVariant { IG_GENERIC = 0, IG_DMA, IG_HALO_8x32, IG_HALO_16x16 };
+
+// ONE place that decides which kernel serves a shape (also used by the statistics-row query).
+static IgemmVariant pick_variant(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int mul, int kmul, int off,
+                                 int div, int up, int dtype) {
+  if (dtype != MI355_BF16) return IG_GENERIC;
+  static const int force_generic = getenv("MI355_IGEMM_VARIANT") ? atoi(getenv("MI355_IGEMM_VARIANT")) == 0 : 0;
+  if (force_generic) return IG_GENERIC;
+  const int Hlog = up ? 2 * Hi : Hi, Wlog = up ? 2 * Wi : Wi;
+  // 3x3 stride-1 pad-1 forward / data gradient on tile-divisible images: halo-patch kernel
+  const bool is3x3s1 = KH == 3 && KW == 3 && mul == 1 && div == 1 && Ho == Hlog && Wo == Wlog &&
+                       ((kmul == 1 && off == -1) || (kmul == -1 && off == 1 && !up));
+  if (is3x3s1 && Co % 64 == 0) {
+    if (Wo % 32 == 0 && Ho % 8 == 0) return IG_HALO_8x32;
+    if (Wo % 16 == 0 && Ho % 16 == 0) return IG_HALO_16x16;
+  }
+  if (Co % 64 != 0 && Ci % 64 != 0) return IG_GENERIC;      // 32-wide tile with a 32-deep slab: too few DMA pieces per wave
+  return IG_DMA;
+}
+
+extern "C" int mi355_conv2d_igemm_stat_rows(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int mul,
+                                            int kmul, int off, int div, int up, int dtype) {
+  switch (pick_variant(Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up, dtype)) {
+    case IG_HALO_8x32: return N * (Ho / 8) * (Wo / 32);
+    case IG_HALO_16x16: return N * (Ho / 16) * (Wo / 16);
+    case IG_DMA: return ceil_div((long long)N * Ho * Wo, 128);
+    default: return 0;       // generic kernel: no fused statistics, run mi355_bn_stats
+  }
+}
+
 extern "C" int mi355_conv2d_igemm(const void* in, const void* wk, const float* bias, void* out, int N, int Hi, int Wi,
                                   int Ci, int ldi, int Ho, int Wo, int Co, int ldo, int KH, int KW, int mul, int kmul,
-                                  int off, int div, int up, int accumulate, int dtype, mi355_stream_t s) {
+                                  int off, int div, int up, int accumulate, float* stats, int dtype, mi355_stream_t s) {
   MI355_CHECK_ARG(in && wk && out, "conv2d_igemm: null pointer");
   MI355_CHECK_ARG(N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && KH > 0 && KW > 0, "conv2d_igemm: bad extent");
   MI355_CHECK_ARG(div == 1 || div == 2 || div == 4, "conv2d_igemm: div must be 1, 2 or 4 (got %d)", div);
@@ -488,10 +550,16 @@ extern "C" int mi355_conv2d_igemm(const void* in, const void* wk, const float* b
   MI355_CHECK_ARG(ldi >= Ci && ldo >= Co, "conv2d_igemm: channel stride smaller than channel count");
   MI355_CHECK_ARG((long long)N * Ho * Wo < (1ll << 31) && (long long)N * Hi * Wi < (1ll << 31),
                   "conv2d_igemm: pixel count overflows int32");
+  MI355_CHECK_ARG(dtype == MI355_BF16 || dtype == MI355_F32, "conv2d_igemm: unknown dtype %d", dtype);
   const int esz = dtype == MI355_BF16 ? 2 : 4;
   MI355_CHECK_ARG(((uintptr_t)in % 16) == 0 && ((uintptr_t)wk % 16) == 0 && ((uintptr_t)out % 16) == 0 &&
                       (ldi * esz) % 16 == 0 && (ldo * esz) % 16 == 0,
                   "conv2d_igemm: pointers / channel strides must be 16-byte aligned");
+  MI355_CHECK_ARG(Ci % (dtype == MI355_BF16 ? 32 : 16) == 0, "conv2d_igemm: Ci=%d must be a multiple of %d", Ci,
+                  dtype == MI355_BF16 ? 32 : 16);
+  const IgemmVariant v = pick_variant(Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up, dtype);
+  MI355_CHECK_ARG(!stats || (v != IG_GENERIC && !accumulate),
+                  "conv2d_igemm: fused statistics are not available for this shape/dtype (mi355_conv2d_igemm_stat_rows == 0)");
   ConvArgs a;
   a.in = in; a.wk = wk; a.bias = bias; a.out = out;
   a.N = N; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.ldi = ldi;
@@ -500,45 +568,24 @@ extern "C" int mi355_conv2d_igemm(const void* in, const void* wk, const float* b
   a.dshift = div == 1 ? 0 : (div == 2 ? 1 : 2);
   a.up = up ? 1 : 0;
   a.accumulate = accumulate;
+  a.stats = stats;
   a.M = N * Ho * Wo;
   a.HoWo = Ho * Wo;
   a.Hlog = up ? 2 * Hi : Hi;
   a.Wlog = up ? 2 * Wi : Wi;
   hipStream_t st = (hipStream_t)s;
-  if (dtype == MI355_BF16) {
-    MI355_CHECK_ARG(Ci % 32 == 0, "conv2d_igemm: bf16 needs Ci %% 32 == 0 (got %d)", Ci);
-    static const int variant = getenv("MI355_IGEMM_VARIANT") ? atoi(getenv("MI355_IGEMM_VARIANT")) : 1;
-    if (variant == 0) {          // register-staged reference kernel
-      if (Ci % 64 == 0) return launch_bn<bf16_t, 64>(a, st);
-      return launch_bn<bf16_t, 32>(a, st);
-    }
-    // 3x3 stride-1 pad-1 forward / data gradient on tile-divisible images: halo-patch kernel
-    const bool is3x3s1 = KH == 3 && KW == 3 && mul == 1 && div == 1 && Ho == a.Hlog && Wo == a.Wlog &&
-                         ((kmul == 1 && off == -1) || (kmul == -1 && off == 1 && !up));
-    if (variant == 1 && is3x3s1 && Co % 64 == 0) {
-      if (Wo % 32 == 0 && Ho % 8 == 0) return Co % 128 == 0 ? launch_halo<128, 8, 32>(a, st) : launch_halo<64, 8, 32>(a, st);
-      if (Wo % 16 == 0 && Ho % 16 == 0) return Co % 128 == 0 ? launch_halo<128, 16, 16>(a, st) : launch_halo<64, 16, 16>(a, st);
-    }
-    // measured on MI355X (AttentionUNet shapes): the 2-deep BK=64 ring (2 workgroups/CU) wins for 128-wide
-    // tiles, the 3-deep BK=32 ring (3-4 workgroups/CU) for 64-wide tiles and for Ci % 64 != 0
-    const bool k64 = Ci % 64 == 0;
-    if (Co % 128 == 0) {
-      if (variant == 2 && k64) return launch_dma<128, 64, 3>(a, st);
-      if (variant == 3) return launch_dma<128, 32, 4>(a, st);
-      if (variant == 5 || !k64) return launch_dma<128, 32, 3>(a, st);
-      return launch_dma<128, 64, 2>(a, st);
-    }
-    if (Co % 64 == 0) {
-      if (variant == 2 && k64) return launch_dma<64, 64, 3>(a, st);
-      if (variant == 3) return launch_dma<64, 32, 4>(a, st);
-      if (variant == 4 && k64) return launch_dma<64, 64, 2>(a, st);
-      return launch_dma<64, 32, 3>(a, st);
-    }
-    if (k64) return launch_dma<32, 64, 3>(a, st);
-    return launch_bn<bf16_t, 32>(a, st);
-  } else if (dtype == MI355_F32) {
-    MI355_CHECK_ARG(Ci % 16 == 0, "conv2d_igemm: fp32 needs Ci %% 16 == 0 (got %d)", Ci);
-    return launch_bn<float, 16>(a, st);
+  const bool k64 = Ci % 64 == 0;
+  switch (v) {
+    case IG_HALO_8x32: return Co % 128 == 0 ? launch_halo<128, 8, 32>(a, st) : launch_halo<64, 8, 32>(a, st);
+    case IG_HALO_16x16: return Co % 128 == 0 ? launch_halo<128, 16, 16>(a, st) : launch_halo<64, 16, 16>(a, st);
+    case IG_DMA:
+      // measured on MI355X (AttentionUNet shapes): the 2-deep BK=64 ring (2 workgroups/CU) wins for 128-wide tiles,
+      // the 3-deep BK=32 ring (3-4 workgroups/CU) for 64-wide tiles and for Ci % 64 != 0
+      if (Co % 128 == 0) return k64 ? launch_dma<128, 64, 2>(a, st) : launch_dma<128, 32, 3>(a, st);
+      if (Co % 64 == 0) return launch_dma<64, 32, 3>(a, st);
+      return launch_dma<32, 64, 3>(a, st);
+    default:
+      if (dtype == MI355_BF16) return k64 ? launch_bn<bf16_t, 64>(a, st) : launch_bn<bf16_t, 32>(a, st);
+      return launch_bn<float, 16>(a, st);
   }
-  MI355_FAIL(MI355_ERR_UNSUPPORTED, "conv2d_igemm: unknown dtype %d", dtype);
 }

@@ -355,8 +355,10 @@ class Builder:
         hl, wl = (2 * x.H, 2 * x.W) if up else (x.H, x.W)
         return k, s, p, (hl + 2 * p - k) // s + 1, (wl + 2 * p - k) // s + 1
 
-    def conv_raw(self, x, conv, up=False, out=None):
-        """y = conv(x) (+bias), raw output in the compute dtype; returns (y, bwd(dy, bias_done))."""
+    def conv_raw(self, x, conv, up=False, out=None, stats=False):
+        """y = conv(x) (+bias), raw output in the compute dtype; returns (y, bwd(dy, bias_done)).  With
+        ``stats`` the BatchNorm partial sums of y are produced by the conv epilogue when the kernel supports
+        it (``self._last_stat_rows`` > 0 afterwards)."""
         k, s, p, Ho, Wo = self._conv_geom(x, conv, up)
         Co = conv.out_channels
         assert x.C >= conv.in_channels and (x.C == conv.in_channels or conv.in_channels < CPAD), (x.C, conv.in_channels)
@@ -364,8 +366,15 @@ class Builder:
         y = out if out is not None else self.new_tensor(x.N, Ho, Wo, Co)
         assert (y.N, y.H, y.W, y.C) == (x.N, Ho, Wo, Co)
         flops = 2 * x.N * Ho * Wo * Co * k * k * conv.in_channels
+        stat_part = None
+        self._last_stat_rows = 0
+        if stats and self.training:
+            rows = lib.mi355_conv2d_igemm_stat_rows(x.N, x.H, x.W, x.C, Ho, Wo, Co, k, k, s, 1, -p, 1, 1 if up else 0, self.code)
+            if rows > 0:            # the kernel serving this shape folds the BatchNorm statistics into its epilogue
+                stat_part = self.ws_f32(rows * 2 * Co)
+                self._last_stat_rows = rows
         self.fwd.append(Launch("mi355_conv2d_igemm", x, wf, conv.bias, y, x.N, x.H, x.W, x.C, x.ld, Ho, Wo, Co, y.ld,
-                               k, k, s, 1, -p, 1, 1 if up else 0, 0, self.code, flops=flops,
+                               k, k, s, 1, -p, 1, 1 if up else 0, 0, stat_part, self.code, flops=flops,
                                tag=self.igemm_tag(Co, x.C, k, s, Ho, Wo, False, up)))
         y.needs_grad = x.needs_grad or conv.weight.requires_grad
 
@@ -383,7 +392,7 @@ class Builder:
                 if up:
                     tmp = self.new_tensor(x.N, 2 * x.H, 2 * x.W, x.C)
                     self.bwd.append(Launch("mi355_conv2d_igemm", dy, wb, None, tmp, x.N, Ho, Wo, Co, dy.ld, 2 * x.H, 2 * x.W,
-                                           x.C, tmp.ld, k, k, 1, -1, p, s, 0, 0, self.code, flops=flops,
+                                           x.C, tmp.ld, k, k, 1, -1, p, s, 0, 0, None, self.code, flops=flops,
                                            tag=self.igemm_tag(x.C, Co, k, s, 2 * x.H, 2 * x.W, True, False)))
                     acc = self.acc_flag(x)
                     xg = self.grad_of(x)
@@ -392,7 +401,7 @@ class Builder:
                     acc = self.acc_flag(x)
                     xg = self.grad_of(x)
                     self.bwd.append(Launch("mi355_conv2d_igemm", dy, wb, None, xg, x.N, Ho, Wo, Co, dy.ld, x.H, x.W, x.C,
-                                           xg.ld, k, k, 1, -1, p, s, 0, acc, self.code, flops=flops,
+                                           xg.ld, k, k, 1, -1, p, s, 0, acc, None, self.code, flops=flops,
                                            tag=self.igemm_tag(x.C, Co, k, s, x.H, x.W, True, False)))
         return y, bwd
 
@@ -427,15 +436,20 @@ class Builder:
         self.bwd.append(Launch("mi355_colsum_finalize", part, nb, 1, dy.C, ref, beta))
 
     # ---- batch norm state ---------------------------------------------------------------------------------
-    def _bn_coeffs(self, y, bn):
-        """Emit statistics (train) or running-stat coefficients (eval); returns dict of fp32 buffers."""
+    def _bn_coeffs(self, y, bn, fused_rows=0):
+        """Emit statistics (train) or running-stat coefficients (eval); returns dict of fp32 buffers.
+        ``fused_rows`` > 0: the producing conv already left that many partial rows in the f32 workspace."""
         C = bn.num_features
         st = {k: self.f32(C) for k in ("scale", "shift", "mean", "invstd")}
         self.see(bn.weight, bn.bias)
         if self.training:
-            nb = lib.mi355_rowreduce_blocks(y.M)
-            part = self.ws_f32(nb * 2 * C)
-            self.fwd.append(Launch("mi355_bn_stats", y, part, y.M, C, y.ld, self.code))
+            if fused_rows > 0:
+                nb = fused_rows
+                part = self.ws_f32(nb * 2 * C)
+            else:
+                nb = lib.mi355_rowreduce_blocks(y.M)
+                part = self.ws_f32(nb * 2 * C)
+                self.fwd.append(Launch("mi355_bn_stats", y, part, y.M, C, y.ld, self.code))
             mom = bn.momentum if bn.momentum is not None else 0.1
             track = bn.track_running_stats
             self.fwd.append(Launch("mi355_bn_finalize", part, nb, y.M, C, bn.weight, bn.bias,
@@ -496,8 +510,8 @@ class Builder:
     # ---- fused block ops -------------------------------------------------------------------------------------
     def conv_bn_act(self, x, conv, bn, act=True, up=False, out=None, res=None):
         """act(bn(conv(x)) [+ res]) — the workhorse (AttentionUNet.py:4-13,15-27; ResNet.py:36-44)."""
-        y, conv_bwd = self.conv_raw(x, conv, up)
-        st = self._bn_coeffs(y, bn)
+        y, conv_bwd = self.conv_raw(x, conv, up, stats=True)
+        st = self._bn_coeffs(y, bn, self._last_stat_rows)
         a = out if out is not None else self.new_tensor(y.N, y.H, y.W, y.C)
         self.fwd.append(Launch("mi355_bn_act", y, y.ld, st["scale"], st["shift"], None, 0, None, None,
                                res, res.ld if res is not None else 0, a, a.ld, y.M, y.C, 1 if act else 0, self.code))
@@ -562,7 +576,7 @@ class Builder:
         Ho, Wo = x.H * s, x.W * s
         y = out if out is not None else self.new_tensor(x.N, Ho, Wo, Co)
         self.fwd.append(Launch("mi355_conv2d_igemm", x, wf, mod.bias, y, x.N, x.H, x.W, Ci, x.ld, Ho, Wo, Co, y.ld, k, k,
-                               1, -1, 0, s, 0, 0, self.code))
+                               1, -1, 0, s, 0, 0, None, self.code))
         y.needs_grad = x.needs_grad or mod.weight.requires_grad
 
         def rule():
@@ -583,7 +597,7 @@ class Builder:
                 acc = self.acc_flag(x)
                 xg = self.grad_of(x)
                 self.bwd.append(Launch("mi355_conv2d_igemm", dy, wb, None, xg, x.N, Ho, Wo, Co, dy.ld, x.H, x.W, Ci, xg.ld,
-                                       k, k, s, 1, 0, 1, 0, acc, self.code))
+                                       k, k, s, 1, 0, 1, 0, acc, None, self.code))
         self.rule(rule)
         return y
 
@@ -651,10 +665,10 @@ class Builder:
         cp, bp = att.psi[0], att.psi[1]
         F_int = cg.out_channels
         M = x.M
-        g1, g1_bwd = self.conv_raw(g, cg)
-        sg = self._bn_coeffs(g1, bg)
-        x1, x1_bwd = self.conv_raw(x, cx)
-        sx = self._bn_coeffs(x1, bx)
+        g1, g1_bwd = self.conv_raw(g, cg, stats=True)
+        sg = self._bn_coeffs(g1, bg, self._last_stat_rows)
+        x1, x1_bwd = self.conv_raw(x, cx, stats=True)
+        sx = self._bn_coeffs(x1, bx, self._last_stat_rows)
         p = self.new_tensor(x.N, x.H, x.W, F_int)
         self.fwd.append(Launch("mi355_bn_act", g1, g1.ld, sg["scale"], sg["shift"], x1, x1.ld, sx["scale"], sx["shift"],
                                None, 0, p, p.ld, M, F_int, 1, self.code))

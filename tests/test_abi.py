@@ -11,7 +11,7 @@ from mi355 import lib as L
 def test_header_parses():
     protos = L.parse_header()
     assert len(protos) >= 40
-    assert "mi355_conv2d_igemm" in protos and len(protos["mi355_conv2d_igemm"][1]) == 23
+    assert "mi355_conv2d_igemm" in protos and len(protos["mi355_conv2d_igemm"][1]) == 24
     for name, (ret, args) in protos.items():
         assert name.startswith("mi355_")
 
@@ -39,5 +39,5 @@ def test_argument_errors_are_reported_without_a_gpu():
     fn = dll.mi355_conv2d_igemm
     fn.restype = ctypes.c_int
     fn.argtypes = [t for t, _ in L.parse_header()["mi355_conv2d_igemm"][1]]
-    rc = fn(None, None, None, None, 1, 4, 4, 32, 32, 4, 4, 32, 32, 3, 3, 1, 1, -1, 1, 0, 0, 0, None)
+    rc = fn(None, None, None, None, 1, 4, 4, 32, 32, 4, 4, 32, 32, 3, 3, 1, 1, -1, 1, 0, 0, None, 0, None)
     assert rc == -1 and b"null" in dll.mi355_last_error()

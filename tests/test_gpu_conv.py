@@ -48,7 +48,7 @@ def test_conv_fwd(case, dtype):
     xd = to_nhwc(x, dtype)
     wf, _ = pack_w(w, dtype)
     y = torch.full((n, ho, wo, co), float("nan"), dtype=dtype, device=DEV)
-    lib.mi355_conv2d_igemm(xd, wf, b.to(DEV), y, n, h, w_, ci, ci, ho, wo, co, co, k, k, s, 1, -p, 1, up, 0,
+    lib.mi355_conv2d_igemm(xd, wf, b.to(DEV), y, n, h, w_, ci, ci, ho, wo, co, co, k, k, s, 1, -p, 1, up, 0, None,
                            DTYPE_CODE[dtype])
     torch.cuda.synchronize()
     assert rel_err(from_nhwc(y), ref) < TOL[dtype]
@@ -70,7 +70,7 @@ def test_conv_dgrad(case, dtype):
     _, wb = pack_w(w, dtype)
     dx = torch.full((n, h, w_, ci), float("nan"), dtype=dtype, device=DEV)
     # data gradient = gather over dy with the [Ci][tap][Co] pack: mul=1,kmul=-1,off=+p,div=s
-    lib.mi355_conv2d_igemm(dyd, wb, None, dx, n, ho, wo, co, co, h, w_, ci, ci, k, k, 1, -1, p, s, 0, 0,
+    lib.mi355_conv2d_igemm(dyd, wb, None, dx, n, ho, wo, co, co, h, w_, ci, ci, k, k, 1, -1, p, s, 0, 0, None,
                            DTYPE_CODE[dtype])
     torch.cuda.synchronize()
     assert rel_err(from_nhwc(dx), ref) < TOL[dtype]
@@ -89,7 +89,7 @@ def test_conv_strided_slices_and_accumulate(dtype):
     out = base.clone().to(DEV)
     es = out.element_size()
     lib.mi355_conv2d_igemm(xin.data_ptr() + 64 * es, wf, None, out.data_ptr() + 32 * es, n, h, w_, ci, 96, h, w_, co,
-                           160, 3, 3, 1, 1, -1, 1, 0, 1, DTYPE_CODE[dtype])
+                           160, 3, 3, 1, 1, -1, 1, 0, 1, None, DTYPE_CODE[dtype])
     torch.cuda.synchronize()
     got = out.float().cpu()
     exp = base.float().clone(); exp[..., 32:96] += ref.permute(0, 2, 3, 1)
@@ -107,7 +107,7 @@ def test_conv_transpose_2x2(dtype):
     wf, _ = pack_w(w, dtype, transposed=True)          # [Co][tap][Ci]
     y = torch.empty(n, 2 * h, 2 * w_, co, dtype=dtype, device=DEV)
     lib.mi355_conv2d_igemm(to_nhwc(x, dtype), wf, b.to(DEV), y, n, h, w_, ci, ci, 2 * h, 2 * w_, co, co, 2, 2, 1, -1, 0,
-                           2, 0, 0, DTYPE_CODE[dtype])
+                           2, 0, 0, None, DTYPE_CODE[dtype])
     torch.cuda.synchronize()
     assert rel_err(from_nhwc(y), ref) < TOL[dtype]
 
@@ -115,7 +115,7 @@ def test_conv_transpose_2x2(dtype):
 def test_bad_args_raise():
     x = torch.zeros(1, 4, 4, 24, device=DEV)
     with pytest.raises(RuntimeError, match="Ci"):
-        lib.mi355_conv2d_igemm(x, x, None, x, 1, 4, 4, 24, 24, 4, 4, 32, 32, 3, 3, 1, 1, -1, 1, 0, 0, 0)
+        lib.mi355_conv2d_igemm(x, x, None, x, 1, 4, 4, 24, 24, 4, 4, 32, 32, 3, 3, 1, 1, -1, 1, 0, 0, None, 0)
 
 
 WG_CASES = [  # N, Ci, H, W, Co, K, stride, pad, up
@@ -166,3 +166,32 @@ def test_conv_wgrad(case, dtype):
         lib.mi355_conv2d_wgrad_reduce(ws, sp, dw, co, cip, ci, k, k, 0, 1.0)   # beta = 1 accumulates
         torch.cuda.synchronize()
         assert rel_err(dw.cpu(), 2 * ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("case", [(2, 64, 16, 32, 128, 3, 1, 1, 0), (2, 96, 16, 16, 64, 3, 1, 1, 0), (3, 64, 9, 7, 64, 1, 1, 0, 0),
+                                  (2, 64, 8, 16, 128, 3, 1, 1, 1), (1, 32, 5, 5, 128, 3, 2, 1, 0)])
+def test_conv_fused_bn_statistics(case):
+    """bf16 kernels fold the BatchNorm partial sums of the (rounded) outputs into their epilogue."""
+    dtype = torch.bfloat16
+    n, ci, h, w_, co, k, s, p, up = case
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(n, ci, h, w_, generator=g); w = torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5
+    b = torch.randn(co, generator=g)
+    ref = _conv_ref(q(x, dtype), q(w, dtype), b, s, p, up)
+    ho, wo = ref.shape[2], ref.shape[3]
+    code = DTYPE_CODE[dtype]
+    rows = lib.mi355_conv2d_igemm_stat_rows(n, h, w_, ci, ho, wo, co, k, k, s, 1, -p, 1, up, code)
+    assert rows > 0
+    part = torch.full((rows * 2 * co,), float("nan"), device=DEV)
+    y = torch.empty(n, ho, wo, co, dtype=dtype, device=DEV)
+    wf, _ = pack_w(w, dtype)
+    lib.mi355_conv2d_igemm(to_nhwc(x, dtype), wf, b.to(DEV), y, n, h, w_, ci, ci, ho, wo, co, co, k, k, s, 1, -p, 1, up, 0, part, code)
+    sc, sh, mu, isd = (torch.empty(co, device=DEV) for _ in range(4))
+    ones, zeros = torch.ones(co, device=DEV), torch.zeros(co, device=DEV)
+    lib.mi355_bn_finalize(part, rows, n * ho * wo, co, ones, zeros, None, None, None, 0.1, 1e-5, sc, sh, mu, isd)
+    torch.cuda.synchronize()
+    yf = from_nhwc(y)
+    assert rel_err(yf, ref) < TOL[dtype]
+    assert rel_err(mu.cpu(), yf.mean((0, 2, 3))) < 1e-4
+    assert rel_err(isd.cpu(), 1 / torch.sqrt(yf.var((0, 2, 3), unbiased=False) + 1e-5)) < 1e-4
+    assert lib.mi355_conv2d_igemm_stat_rows(n, h, w_, ci, ho, wo, co, k, k, s, 1, -p, 1, up, DTYPE_CODE[torch.float32]) == 0

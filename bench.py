@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--graph", type=int, default=0, help="capture the step into a hipGraph (1) or run eagerly (0)")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel time table to stderr")
+    ap.add_argument("--force-dp", action="store_true", help="exercise the RCCL data-parallel path even with one rank")
     args = ap.parse_args()
 
     t_start = time.perf_counter()
@@ -119,8 +120,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dp = world > 1 or args.force_dp
+    if use_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
 
     from mi355 import nn as mnn, optim as moptim
@@ -132,7 +137,7 @@ def main():
     model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model = model.to(device).train()
     model.engine._check_storage()
-    dp = DataParallel(model) if world > 1 else None
+    dp = DataParallel(model, force=args.force_dp) if use_dp else None
     crit = mnn.BCEWithLogitsLoss()
     opt = moptim.AdamW(model.parameters(), lr=1e-6, weight_decay=5e-4)
     inv_scale = dp.inv_scale if dp is not None else 1.0
@@ -234,7 +239,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline(args.size, 2, 2)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dp:
         dist.destroy_process_group()
 
 

@@ -17,7 +17,7 @@ from . import graph
 
 
 class DataParallel:
-    def __init__(self, net, bucket_mb: float = 32.0, overlap: bool = True, process_group=None):
+    def __init__(self, net, bucket_mb: float = 32.0, overlap: bool = True, process_group=None, force: bool = False):
         self.net = net
         self.engine = net.engine
         self.group = process_group
@@ -28,7 +28,7 @@ class DataParallel:
         self.comm_stream = None
         self.inv_scale = 1.0 / self.world
         self.run_calls = graph.Plan._run      # injectable (CPU tests replace the kernel launcher)
-        if self.world > 1:
+        if self.world > 1 or force:
             self.engine.bwd_runner = self._run_backward
 
     # ---- bucket schedule: (launch index after which the bucket is complete, lo, hi) -----------------

@@ -1,0 +1,83 @@
+"""Training entry point of the MI355X path — the counterpart of the reference's utils/trainer.py
+(a ``__main__`` script: datasets -> loaders -> ``train()`` for each model, trainer.py:163-232).
+
+The reference reads the COVID-19 Radiography dataset through Albumentations/cv2 (absent offline and
+out of scope); this driver keeps its protocol — classification bs=16, segmentation bs=8,
+80/20 split, 20 epochs, lr 1e-6 (trainer.py:28-37,159-160,199-210) — on any ``(x, y)`` datasets and
+defaults to synthetic 256x256 batches so that it runs anywhere:
+
+    python utils/trainer.py --task seg --model attentionunet --epochs 2 --samples 64
+"""
+import argparse
+import os
+import sys
+
+import torch
+from torch.utils.data import DataLoader, TensorDataset, random_split
+
+PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if PKG not in sys.path:
+    sys.path.insert(0, PKG)
+
+from utils.helpers import get_class_model, get_seg_model, train  # noqa: E402
+
+IMG_SIZE = 256
+CLS_MODELS = ["resnet18", "resnet50", "vgg16", "vgg19"]
+SEG_MODELS = ["resnetunet", "attentionunet", "r2unet", "r2attunet"]
+
+
+def synthetic_dataset(task, n, size, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, 3, size, size, generator=g)
+    if task == "cls":
+        return TensorDataset(x, torch.randint(0, 3, (n,), generator=g))
+    yy, xx = torch.meshgrid(torch.arange(size, dtype=torch.float32), torch.arange(size, dtype=torch.float32), indexing="ij")
+    c = torch.rand(n, 4, generator=g)
+    cy, cx = (0.4 + 0.2 * c[:, 0]) * size, (0.4 + 0.2 * c[:, 1]) * size
+    ry, rx = (0.25 + 0.1 * c[:, 2]) * size, (0.25 + 0.1 * c[:, 3]) * size
+    m = ((((yy[None] - cy[:, None, None]) / ry[:, None, None]) ** 2 + ((xx[None] - cx[:, None, None]) / rx[:, None, None]) ** 2) <= 1).float()
+    return TensorDataset(x + m[:, None] * torch.tensor([1.0, -0.7, 0.4]).view(1, 3, 1, 1), m[:, None])
+
+
+def make_loader(ds, bs, shuffle):
+    return DataLoader(ds, batch_size=bs, shuffle=shuffle, num_workers=0, pin_memory=True, drop_last=False)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--task", choices=["cls", "seg", "both"], default="seg")
+    ap.add_argument("--model", default=None, help="one model name; default: every model of the task (trainer.py:163-168)")
+    ap.add_argument("--epochs", type=int, default=20)
+    ap.add_argument("--lr", type=float, default=1e-6)
+    ap.add_argument("--samples", type=int, default=64)
+    ap.add_argument("--size", type=int, default=IMG_SIZE)
+    ap.add_argument("--save-dir", default="weights")
+    args = ap.parse_args()
+    device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    if device.type != "cuda":
+        raise SystemExit("the MI355X path needs a GPU (no CPU fallback)")
+    results = {}
+    for task in (["cls", "seg"] if args.task == "both" else [args.task]):
+        names = [args.model] if args.model else (CLS_MODELS if task == "cls" else SEG_MODELS)
+        full = synthetic_dataset(task, args.samples, args.size)
+        n_train = int(0.8 * len(full))
+        tr, va = random_split(full, [n_train, len(full) - n_train])
+        bs = 16 if task == "cls" else 8
+        train_dl, val_dl = make_loader(tr, bs, True), make_loader(va, bs, False)
+        for name in names:
+            print(f"\n{'=' * 20} {task.upper()} :: {name} {'=' * 20}")
+            if task == "cls":
+                model, head = get_class_model(name)
+                best = train(model, train_dl, val_dl, device, args.epochs, args.lr, name, os.path.join(args.save_dir, "classification_models"),
+                             seg=False, cls_head_name=head)
+            else:
+                model = get_seg_model(name)
+                best = train(model, train_dl, val_dl, device, args.epochs, args.lr, name, os.path.join(args.save_dir, "segmentation_models"), seg=True)
+            results[(task, name)] = best
+    print("\n===== SUMMARY =====")
+    for (task, name), best in results.items():
+        print(f"{task:>4} {name:<14} best {'val loss' if task == 'seg' else 'val acc'}: {best:.4f}")
+
+
+if __name__ == "__main__":
+    main()

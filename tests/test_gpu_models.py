@@ -217,3 +217,94 @@ def test_state_dict_roundtrip_and_no_cpu_fallback():
     with torch.no_grad():
         b = m2(x)
     assert torch.equal(a, b)
+
+
+def test_resnet_unet_matches_oracle_fp32():
+    """ResNetUnet (config 2).  The reference class needs torchvision (absent), so this model is checked
+    against the oracle only (parity unpinned at the torchvision-encoder boundary): logits,
+    loss, frozen-encoder semantics, BN buffers and — anchored on fp64 like the other nets — the decoder
+    gradients, including both ConvTranspose2d backward paths."""
+    from mi355 import nn as mnn
+    from models.segmentation_models.ResnetUnet import ResNetUnet
+    name = "ResNetUnet"
+    sd = nets.closed_form_state(name)
+    m = ResNetUnet()
+    m.load_state_dict(sd)
+    m.compute_dtype = torch.float32
+    m = m.to(DEV)
+    x, mask = otrain.closed_form_input(2, 64)
+    m.eval()
+    with torch.no_grad():
+        ev = m(x.to(DEV)).cpu()
+        ev_ref = nets.resnet_unet({k: v.clone() for k, v in sd.items()}, x, False)
+    assert _rel(ev.numpy(), ev_ref.numpy()) < RTOL
+    m.train()
+    out = m(x.to(DEV))
+    loss = mnn.BCEWithLogitsLoss()(out, mask.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    frozen = {k for k, p in m.named_parameters() if not p.requires_grad}
+    assert frozen and all(k.startswith("encoder") for k in frozen)
+    assert all(p.grad is None for k, p in m.named_parameters() if k in frozen)
+
+    def oracle(dtype):
+        s = {k: (v.to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        pk = [k for k in nets.param_keys(s) if k not in frozen]
+        for k in pk:
+            s[k].requires_grad_(True)
+        o = nets.resnet_unet(s, x.to(dtype), True)
+        l = otrain.bce_with_logits(o, mask.to(dtype))
+        l.backward()
+        return o.detach(), float(l), {k: s[k].grad for k in pk}, s
+
+    o64, l64, g64, _ = oracle(torch.float64)
+    o32, l32, g32, s32 = oracle(torch.float32)
+    assert _rel(out.detach().cpu().numpy(), o64.numpy()) < max(RTOL, 4 * _rel(o32.numpy(), o64.numpy()))
+    assert abs(float(loss.detach()) - l64) < RTOL
+    params = dict(m.named_parameters())
+    gmax = max(float(v.abs().max()) for v in g64.values())
+    e_gpu, e_cpu = [], []
+    for k, ref in g64.items():
+        sc = float(ref.abs().max())
+        if sc < 1e-6 * gmax:
+            continue
+        e_gpu.append(float((params[k].grad.cpu().double() - ref).abs().max()) / sc)
+        e_cpu.append(float((g32[k].double() - ref).abs().max()) / sc)
+    assert np.median(e_gpu) <= max(RTOL, 3 * np.median(e_cpu)), (np.median(e_gpu), np.median(e_cpu))
+    assert np.max(e_gpu) <= max(RTOL, 5 * np.max(e_cpu)), (np.max(e_gpu), np.max(e_cpu))
+    msd = m.state_dict()
+    for k, v in s32.items():
+        if k.endswith(("running_mean", "running_var")):
+            assert _rel(msd[k].cpu().numpy(), v.detach().numpy()) < RTOL, k
+
+
+def test_tester_functions_match_oracle_metrics(capsys):
+    """utils.tester (tester.py:92-312 counterpart): metric helpers and the segmentation eval loop."""
+    from torch.utils.data import DataLoader, TensorDataset
+    from utils import tester
+    g = torch.Generator().manual_seed(4)
+    pred = torch.rand(1, 40, 40, generator=g); tgt = (torch.rand(1, 40, 40, generator=g) > 0.6).float()
+    ref = otrain.seg_metrics(pred, tgt)
+    got_cpu = tester.calculate_segmentation_metrics(pred, tgt)
+    got_gpu = tester.calculate_segmentation_metrics(pred.to(DEV), tgt.to(DEV))
+    for k in ref:
+        assert abs(ref[k] - got_cpu[k]) < 1e-9 and abs(ref[k] - got_gpu[k]) < 1e-4, k
+    assert abs(tester.calculate_dice(pred.to(DEV), tgt.to(DEV)) * 100 - ref["dice"]) < 1e-4
+    m, sd, _ = _build("AttentionUNet", torch.float32)
+    xs, ms = zip(*[otrain.synthetic_batch(3, 32, seed=s) for s in (5, 6)])
+    dl = DataLoader(TensorDataset(torch.cat(xs), torch.cat(ms)), batch_size=3)
+    avg = tester.test_segmentation_model(m, dl, torch.device(DEV), "AttentionUNet")
+    capsys.readouterr()
+    tot = {k: 0.0 for k in avg}
+    with torch.no_grad():
+        for x_, m_ in zip(xs, ms):
+            o = torch.sigmoid(nets.attention_unet({k: v.clone() for k, v in sd.items()}, x_, False))
+            for i in range(o.shape[0]):
+                mm = otrain.seg_metrics(o[i], m_[i])
+                for k in tot:
+                    tot[k] += mm[k] / 6
+    for k in avg:
+        assert abs(avg[k] - tot[k]) < 0.2, (k, avg[k], tot[k])        # percent; a handful of pixels sit at p = 0.5 +- 1e-4
+    pr = np.array([0, 1, 2, 2, 1, 0, 0]); lb = np.array([0, 1, 1, 2, 1, 2, 0])
+    cm = tester.calculate_classification_metrics(pr, lb)
+    assert abs(cm["accuracy"] - 100 * 5 / 7) < 1e-9 and cm["confusion_matrix"].sum() == 7

@@ -68,11 +68,28 @@ def profile_plan(plan, x, stream, reps=2):
         torch.cuda.synchronize()
         for l, e0, e1 in recs:
             key = l.tag or l.name
-            a = agg.setdefault(key, [0.0, 0, 0.0])
+            a = agg.setdefault(key, [0.0, 0, 0.0, 0.0])
             a[0] += e0.elapsed_time(e1)
             a[1] += 1
             a[2] += l.flops
+            a[3] += l.bytes
     return agg
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC pass (profiles/*pmc_traffic.json:
+    separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE doubled as the gfx950 guide
+    prescribes).  PMC counters cannot be read from inside the process, hence the indirection; None if absent."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            e = d["kernels"].get(kernel)
+            if e:
+                return int(e["hbm_MB_per_launch"] * 1e6), os.path.relpath(f, ROOT)
+        except Exception:  # noqa: BLE001
+            continue
+    return None, None
 
 
 def cpu_baseline(hw, bs, steps):
@@ -218,17 +235,20 @@ def main():
         if args.kernel_table:
             print(f"{'kernel / launcher':58s} {'ms/step':>9s} {'launches':>8s} {'TFLOP/s':>9s} {'share':>6s}", file=sys.stderr)
             reps = 2
-            for k, (ms_, n, fl) in ranked[:25]:
+            for k, (ms_, n, fl, _) in ranked[:25]:
                 tf = fl / (ms_ * 1e-3) / 1e12 if fl else 0.0
                 print(f"{k:58s} {ms_ / reps:9.3f} {n // reps:8d} {tf:9.1f} {ms_ / total:6.1%}", file=sys.stderr)
             print(f"{'sum of plan launches':58s} {total / reps:9.3f}", file=sys.stderr)
-        k, (ms_, n, fl) = ranked[0]
+        k, (ms_, n, fl, nb) = ranked[0]
+        traffic, traffic_src = pmc_traffic(k)
         if fl:
             ach = fl / (ms_ * 1e-3) / 1e12
             peak = PEAK_TFLOPS[args.dtype]
             result["roofline"] = {"bound": "mfma", "kernel": k, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                                  "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": n // 2,
-                                  "avg_launch_ms": round(ms_ / n, 4), "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3),
+                                  "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC)",
+                                  "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(nb / n),
+                                  "launches_per_step": n // 2, "avg_launch_ms": round(ms_ / n, 4),
+                                  "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3),
                                   "share_of_plan_time": round(ms_ / total, 3)}
         else:
             result["roofline"] = {"bound": "hbm", "kernel": k, "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None,

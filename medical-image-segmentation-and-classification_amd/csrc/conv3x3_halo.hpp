@@ -8,6 +8,7 @@
 // is re-streamed (3-deep ring, counted s_waitcnt vmcnt across raw s_barriers).  L2->LDS traffic per
 // MFMA drops ~3x versus the im2col-style gather, DMA-issue and address VALU per MFMA ~3x.
 //   (nearest x2 up-sampling of the input is folded into the patch gather: source pixel = logical >> 1)
+// (s_setprio(1) around the MFMA cluster was measured: -3 % with two 4-wave workgroups per CU — not used.)
 //   patch image : pixel-linear, 64 B per pixel, 16-B chunk slot = chunk ^ ((pixel >> 2) & 3)
 //                 (source-side swizzle: conflict-free ds_read_b128 for 32 consecutive pixels)
 //   weight slab : [BN rows][64 B], slot = chunk ^ ((row >> 2) & 3)

@@ -97,10 +97,10 @@ class Launch:
     """One C-ABI call.  `flops` is the ALGORITHMIC work of the launch (2*MACs of the convolution it
     implements, real channel counts) when it is a GEMM-shaped kernel, else 0; `tag` names the kernel
     variant the launcher dispatches to (for per-kernel roofline accounting in bench.py)."""
-    __slots__ = ("name", "args", "flops", "tag")
+    __slots__ = ("name", "args", "flops", "tag", "bytes")
 
-    def __init__(self, name, *args, flops=0, tag=""):
-        self.name, self.args, self.flops, self.tag = name, args, flops, tag
+    def __init__(self, name, *args, flops=0, tag="", nbytes=0):
+        self.name, self.args, self.flops, self.tag, self.bytes = name, args, flops, tag, nbytes
 
 
 class Plan:
@@ -366,6 +366,8 @@ class Builder:
         y = out if out is not None else self.new_tensor(x.N, Ho, Wo, Co)
         assert (y.N, y.H, y.W, y.C) == (x.N, Ho, Wo, Co)
         flops = 2 * x.N * Ho * Wo * Co * k * k * conv.in_channels
+        # algorithmic HBM bytes of one conv launch: input read once, output written once, weights read once
+        nbytes = (x.N * x.H * x.W * x.C + x.N * Ho * Wo * Co + Co * k * k * x.C) * self.esz
         stat_part = None
         self._last_stat_rows = 0
         if stats and self.training:
@@ -374,7 +376,7 @@ class Builder:
                 stat_part = self.ws_f32(rows * 2 * Co)
                 self._last_stat_rows = rows
         self.fwd.append(Launch("mi355_conv2d_igemm", x, wf, conv.bias, y, x.N, x.H, x.W, x.C, x.ld, Ho, Wo, Co, y.ld,
-                               k, k, s, 1, -p, 1, 1 if up else 0, 0, stat_part, self.code, flops=flops,
+                               k, k, s, 1, -p, 1, 1 if up else 0, 0, stat_part, self.code, flops=flops, nbytes=nbytes,
                                tag=self.igemm_tag(Co, x.C, k, s, Ho, Wo, False, up)))
         y.needs_grad = x.needs_grad or conv.weight.requires_grad
 
@@ -383,7 +385,7 @@ class Builder:
                 splits = lib.mi355_conv2d_wgrad_splits(x.N, Ho, Wo, x.C, Co, k, k)
                 ws = self.ws_bytes(splits * Co * k * k * x.C * 4)
                 self.bwd.append(Launch("mi355_conv2d_wgrad", x, dy, ws, splits, x.N, x.H, x.W, x.C, x.ld, Ho, Wo, Co, dy.ld,
-                                       k, k, s, p, 1 if up else 0, self.code, flops=flops, tag=self.wgrad_tag(Co, x.C, k, s, Ho, Wo)))
+                                       k, k, s, p, 1 if up else 0, self.code, flops=flops, nbytes=nbytes, tag=self.wgrad_tag(Co, x.C, k, s, Ho, Wo)))
                 ref, beta = self.pgrad(conv.weight)
                 self.bwd.append(Launch("mi355_conv2d_wgrad_reduce", ws, splits, ref, Co, x.C, conv.in_channels, k, k, 0, beta))
             if conv.bias is not None and conv.bias.requires_grad and not bias_done:
@@ -392,7 +394,7 @@ class Builder:
                 if up:
                     tmp = self.new_tensor(x.N, 2 * x.H, 2 * x.W, x.C)
                     self.bwd.append(Launch("mi355_conv2d_igemm", dy, wb, None, tmp, x.N, Ho, Wo, Co, dy.ld, 2 * x.H, 2 * x.W,
-                                           x.C, tmp.ld, k, k, 1, -1, p, s, 0, 0, None, self.code, flops=flops,
+                                           x.C, tmp.ld, k, k, 1, -1, p, s, 0, 0, None, self.code, flops=flops, nbytes=nbytes,
                                            tag=self.igemm_tag(x.C, Co, k, s, 2 * x.H, 2 * x.W, True, False)))
                     acc = self.acc_flag(x)
                     xg = self.grad_of(x)
@@ -401,7 +403,7 @@ class Builder:
                     acc = self.acc_flag(x)
                     xg = self.grad_of(x)
                     self.bwd.append(Launch("mi355_conv2d_igemm", dy, wb, None, xg, x.N, Ho, Wo, Co, dy.ld, x.H, x.W, x.C,
-                                           xg.ld, k, k, 1, -1, p, s, 0, acc, None, self.code, flops=flops,
+                                           xg.ld, k, k, 1, -1, p, s, 0, acc, None, self.code, flops=flops, nbytes=nbytes,
                                            tag=self.igemm_tag(x.C, Co, k, s, x.H, x.W, True, False)))
         return y, bwd
 

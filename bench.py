@@ -53,7 +53,9 @@ def make_batch(b, hw, seed, device):
 
 def profile_plan(plan, x, stream, reps=2):
     """Instrumented replay: HIP events around every launch of the forward and backward plans."""
-    fwd, bwd = plan.bind(stream)
+    # single-stream resolution on purpose: HIP events on this stream must bracket every kernel (the production
+    # plan forks the weight-gradient launches onto a side stream)
+    fwd, bwd = plan._resolve(plan.pre + plan.fwd, stream), plan._resolve(plan.bwd, stream)
     agg = {}
     for _ in range(reps):
         recs = []

@@ -27,7 +27,7 @@ class DataParallel:
         self._sched = {}
         self.comm_stream = None
         self.inv_scale = 1.0 / self.world
-        self.run_calls = graph.Plan._run      # injectable (CPU tests replace the kernel launcher)
+        self.run_calls = None                 # injectable (CPU tests replace the kernel launcher)
         if self.world > 1 or force:
             self.engine.bwd_runner = self._run_backward
 
@@ -63,27 +63,37 @@ class DataParallel:
     def _run_backward(self, plan, stream):
         calls = plan.bind(stream)[1]
         buckets = self.schedule(plan)
+        run = self.run_calls or plan.run_calls_two_streams
         if not self.overlap or not self.engine.flat_g.is_cuda:
             start = 0
             for ready, lo, hi in buckets:         # same order as the overlapped path, executed serially
-                self.run_calls(calls[start:ready + 1])
+                run(calls[start:ready + 1])
                 start = ready + 1
+                plan.join_side()
                 self._allreduce(lo, hi)
-            self.run_calls(calls[start:])
+            run(calls[start:])
+            plan.join_side()
             return
         if self.comm_stream is None:
             self.comm_stream = torch.cuda.Stream()
         main = torch.cuda.current_stream()
         start = 0
         for ready, lo, hi in buckets:
-            self.run_calls(calls[start:ready + 1])
+            run(calls[start:ready + 1])
             start = ready + 1
             ev = torch.cuda.Event()
             ev.record(main)
+            ev_side = None
+            if plan._side is not None:                      # the bucket's last writer may be a side-stream wgrad reduce
+                ev_side = torch.cuda.Event()
+                ev_side.record(plan._side)
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
+                if ev_side is not None:
+                    self.comm_stream.wait_event(ev_side)
                 self._allreduce(lo, hi)
-        self.run_calls(calls[start:])
+        run(calls[start:])
+        plan.join_side()
         main.wait_stream(self.comm_stream)
 
     def __call__(self, x):

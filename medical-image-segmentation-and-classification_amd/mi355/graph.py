@@ -14,6 +14,7 @@ parameters, packed-weight masters and parameter gradients are fp32.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import List, Optional
 
 import torch
@@ -97,10 +98,11 @@ class Launch:
     """One C-ABI call.  `flops` is the ALGORITHMIC work of the launch (2*MACs of the convolution it
     implements, real channel counts) when it is a GEMM-shaped kernel, else 0; `tag` names the kernel
     variant the launcher dispatches to (for per-kernel roofline accounting in bench.py)."""
-    __slots__ = ("name", "args", "flops", "tag", "bytes")
+    __slots__ = ("name", "args", "flops", "tag", "bytes", "side")
 
-    def __init__(self, name, *args, flops=0, tag="", nbytes=0):
+    def __init__(self, name, *args, flops=0, tag="", nbytes=0, side=False):
         self.name, self.args, self.flops, self.tag, self.bytes = name, args, flops, tag, nbytes
+        self.side = side          # True: may run on the plan's side stream (weight-gradient launches)
 
 
 class Plan:
@@ -121,6 +123,8 @@ class Plan:
         self.param_ptrs = [(p, p.data_ptr()) for p in b.params_seen]
         self.grad_params = list(b.grad_params)   # parameters that receive a gradient, in write order
         self._bound = {}
+        self._side = None
+        self.side_stream_enabled = os.environ.get("MI355_SIDE_STREAM", "1") != "0"
         self.n_launches = (len(self.pre) + len(self.fwd), len(self.bwd))
         # index of the last backward launch that writes each parameter's gradient (data-parallel
         # buckets become ready right after it)
@@ -156,9 +160,21 @@ class Plan:
         return out
 
     def bind(self, stream):
+        """Resolve pointers for `stream`.  Backward launches flagged `side` (weight gradients: they only feed
+        the optimiser) are bound to a private side stream so that the MFMA-bound wgrad kernels overlap the
+        HBM-bound BatchNorm / pooling kernels and the tails of the dgrad kernels of the main chain."""
         key = int(stream or 0)
         if key not in self._bound:
-            self._bound[key] = (self._resolve(self.pre + self.fwd, stream), self._resolve(self.bwd, stream))
+            side = None
+            if self.side_stream_enabled and self.device.type == "cuda" and any(l.side for l in self.bwd):
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=self.device)
+                side = self._side.cuda_stream
+            fwd = self._resolve(self.pre + self.fwd, stream)
+            bwd = []
+            for l in self.bwd:
+                bwd.extend(self._resolve([l], side if (l.side and side is not None) else stream))
+            self._bound[key] = (fwd, bwd)
         return self._bound[key]
 
     @staticmethod
@@ -171,8 +187,30 @@ class Plan:
     def run_forward(self, stream):
         self._run(self.bind(stream)[0])
 
+    def run_calls_two_streams(self, calls):
+        """Run a slice of the bound backward list, forking side-flagged groups onto the side stream."""
+        if self._side is None:
+            self._run(calls)
+            return
+        main = torch.cuda.current_stream()
+        prev_side = False
+        for fn, args, name, l in calls:
+            if l.side and not prev_side:                 # fork: the side group may start once its inputs exist
+                ev = torch.cuda.Event()
+                ev.record(main)
+                self._side.wait_event(ev)
+            prev_side = l.side
+            rc = fn(*args)
+            if rc:
+                raise RuntimeError(f"{name} failed (rc={rc}): {lib.raw('mi355_last_error')().decode()}")
+
+    def join_side(self):
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+
     def run_backward(self, stream):
-        self._run(self.bind(stream)[1])
+        self.run_calls_two_streams(self.bind(stream)[1])
+        self.join_side()
 
     def params_moved(self):
         return any(p.data_ptr() != ptr for p, ptr in self.param_ptrs)
@@ -385,9 +423,10 @@ class Builder:
                 splits = lib.mi355_conv2d_wgrad_splits(x.N, Ho, Wo, x.C, Co, k, k)
                 ws = self.ws_bytes(splits * Co * k * k * x.C * 4)
                 self.bwd.append(Launch("mi355_conv2d_wgrad", x, dy, ws, splits, x.N, x.H, x.W, x.C, x.ld, Ho, Wo, Co, dy.ld,
-                                       k, k, s, p, 1 if up else 0, self.code, flops=flops, nbytes=nbytes, tag=self.wgrad_tag(Co, x.C, k, s, Ho, Wo)))
+                                       k, k, s, p, 1 if up else 0, self.code, flops=flops, nbytes=nbytes, side=True,
+                                       tag=self.wgrad_tag(Co, x.C, k, s, Ho, Wo)))
                 ref, beta = self.pgrad(conv.weight)
-                self.bwd.append(Launch("mi355_conv2d_wgrad_reduce", ws, splits, ref, Co, x.C, conv.in_channels, k, k, 0, beta))
+                self.bwd.append(Launch("mi355_conv2d_wgrad_reduce", ws, splits, ref, Co, x.C, conv.in_channels, k, k, 0, beta, side=True))
             if conv.bias is not None and conv.bias.requires_grad and not bias_done:
                 self.bias_grad_from(dy, conv.bias)
             if x.needs_grad:

@@ -152,7 +152,8 @@ def main():
     from utils.helpers import get_seg_model
 
     torch.manual_seed(0)
-    model = get_seg_model({"AttentionUNet": "attentionunet", "R2AttU_Net": "r2attunet", "R2U_Net": "r2unet"}[args.model])
+    model = get_seg_model({"AttentionUNet": "attentionunet", "R2AttU_Net": "r2attunet", "R2U_Net": "r2unet",
+                           "ResNetUnet": "resnetunet"}[args.model])
     model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model = model.to(device).train()
     model.engine._check_storage()

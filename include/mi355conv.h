@@ -111,7 +111,8 @@ int mi355_bn_finalize(const float* partial, int nblocks, long long M, int C, con
 int mi355_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float eps, int C, float* scale, float* shift,
                          mi355_stream_t s);
-/* y = act(x*scale[c]+shift[c] (+ x2*scale2[c]+shift2[c] | + r)) ; act: 0 none, 1 relu.
+/* y = act(x*scale[c]+shift[c] (+ x2*scale2[c]+shift2[c] | + r)) ; act bit0: ReLU, bit1: add `res` AFTER the
+ * activation (y = relu(bn(x)) + r, the recurrent-block input of R2AttU_Net.py:44) instead of before it.
  * x2/scale2/shift2 optional second normalised operand (attention gate g1+x1,
  * AttentionUNet.py:51); `res` optional already-activated residual (ResNet.py:43). */
 int mi355_bn_act(const void* x, int ldx, const float* scale, const float* shift,

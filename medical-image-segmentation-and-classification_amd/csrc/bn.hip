@@ -159,14 +159,20 @@ template <typename T> struct BnActOp {
 #pragma unroll
       for (int e = 0; e < EPC; ++e) f[e] += to_f32<T>(v2.v[e]) * sc2[e];
     }
-    if (res) {
-      const Vec16<T> vr = ld16<T>(res + row * ldr + c0);
-#pragma unroll
-      for (int e = 0; e < EPC; ++e) f[e] += to_f32<T>(vr.v[e]);
-    }
+    // act bit0: ReLU; bit1: the residual is added AFTER the activation (recurrent block x + relu(bn(.)),
+    // R2AttU_Net.py:44) instead of before it (ResNet.py:43)
+    const bool relu = act & 1, post = act & 2;
+    Vec16<T> vr;
+    if (res) vr = ld16<T>(res + row * ldr + c0);
     Vec16<T> o;
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) o.v[e] = from_f32<T>(act ? fmaxf(f[e], 0.f) : f[e]);
+    for (int e = 0; e < EPC; ++e) {
+      float v = f[e];
+      if (res && !post) v += to_f32<T>(vr.v[e]);
+      if (relu) v = fmaxf(v, 0.f);
+      if (res && post) v += to_f32<T>(vr.v[e]);
+      o.v[e] = from_f32<T>(v);
+    }
     st16<T>(y + row * ldy + c0, o);
   }
 };

@@ -549,19 +549,27 @@ class Builder:
         return Builder._WsOff(ws, off)
 
     # ---- fused block ops -------------------------------------------------------------------------------------
-    def conv_bn_act(self, x, conv, bn, act=True, up=False, out=None, res=None):
-        """act(bn(conv(x)) [+ res]) — the workhorse (AttentionUNet.py:4-13,15-27; ResNet.py:36-44)."""
+    def conv_bn_act(self, x, conv, bn, act=True, up=False, out=None, res=None, post_add=None):
+        """act(bn(conv(x)) [+ res]) [+ post_add] — the workhorse (AttentionUNet.py:4-13,15-27; ResNet.py:36-44;
+        ``post_add``: the recurrent block's x + relu(bn(conv(.))) (R2AttU_Net.py:44) produced in one pass)."""
+        assert res is None or post_add is None
         y, conv_bwd = self.conv_raw(x, conv, up, stats=True)
         st = self._bn_coeffs(y, bn, self._last_stat_rows)
         a = out if out is not None else self.new_tensor(y.N, y.H, y.W, y.C)
+        r = res if res is not None else post_add
+        flags = (1 if act else 0) | (2 if post_add is not None else 0)
         self.fwd.append(Launch("mi355_bn_act", y, y.ld, st["scale"], st["shift"], None, 0, None, None,
-                               res, res.ld if res is not None else 0, a, a.ld, y.M, y.C, 1 if act else 0, self.code))
-        a.needs_grad = y.needs_grad or bn.weight.requires_grad or (res is not None and res.needs_grad)
+                               r, r.ld if r is not None else 0, a, a.ld, y.M, y.C, flags, self.code))
+        a.needs_grad = y.needs_grad or bn.weight.requires_grad or (r is not None and r.needs_grad)
 
         def rule():
             if not a.needs_grad:
                 return
             da = self.grad_of(a)
+            if post_add is not None and post_add.needs_grad:      # d(x + relu(.)) / dx = identity
+                acc = self.acc_flag(post_add)
+                pg = self.grad_of(post_add)
+                self.bwd.append(Launch("mi355_add", da, da.ld, pg if acc else None, pg.ld, pg, pg.ld, y.M, y.C, self.code))
             dy = self._bn_bwd(da, a, y, bn, st, act, dres_to=res, bias=conv.bias)
             conv_bwd(dy, bias_done=True)
         self.rule(rule)

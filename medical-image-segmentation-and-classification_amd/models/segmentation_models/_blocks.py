@@ -51,10 +51,14 @@ class Recurrent_block(nn.Module):
         """x1 = f(x); t times x1 = f(x + x1).  The weight pack is shared; BN statistics, running-stat
         updates and gradients are per application, in application order."""
         conv, bn = self.conv[0], self.conv[1]
-        x1 = g.conv_bn_act(x, conv, bn, act=True)
-        for _ in range(self.t):
-            x1 = g.conv_bn_act(g.add(x, x1), conv, bn, act=True)
-        return x1
+        if self.t == 0:
+            return g.conv_bn_act(x, conv, bn, act=True)
+        # every application but the last emits s = x + relu(bn(conv(.))) directly (the next application's
+        # input); x1 itself is never materialised except as the block output
+        s = g.conv_bn_act(x, conv, bn, act=True, post_add=x)
+        for _ in range(self.t - 1):
+            s = g.conv_bn_act(s, conv, bn, act=True, post_add=x)
+        return g.conv_bn_act(s, conv, bn, act=True)
 
 
 class RRCNN_block(nn.Module):

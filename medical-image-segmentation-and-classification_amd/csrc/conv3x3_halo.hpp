@@ -9,9 +9,13 @@
 // MFMA drops ~3x versus the im2col-style gather, DMA-issue and address VALU per MFMA ~3x.
 //   (nearest x2 up-sampling of the input is folded into the patch gather: source pixel = logical >> 1)
 // (s_setprio(1) around the MFMA cluster was measured: -3 % with two 4-wave workgroups per CU — not used.)
-//   patch image : pixel-linear, 64 B per pixel, 16-B chunk slot = chunk ^ ((pixel >> 2) & 3)
-//                 (source-side swizzle: conflict-free ds_read_b128 for 32 consecutive pixels)
-//   weight slab : [BN rows][64 B], slot = chunk ^ ((row >> 2) & 3)
+//   MFMA        : v_mfma_f32_16x16x32_bf16 — one instruction consumes a whole 32-deep slab of a 16x16 block;
+//                 at equal operand traffic it ran 8 % faster in situ than 32x32x16 (the chip holds a higher
+//                 clock on this shape, MI355X_MICROARCH.md DVFS item 7)
+//   patch image : pixel-linear, 64 B per pixel, 16-B chunk slot = chunk ^ (((pixel >> 2) & 1) << 1)
+//                 (source-side swizzle; conflict-free ds_read_b128 for the 16x16x32 operand map — 16 consecutive
+//                 pixels x 4 k-chunks per wave-instruction — at ANY pixel alignment, i.e. for all nine tap shifts)
+//   weight slab : [BN rows][64 B], same slot rule on the row index
 #pragma once
 #include "common.hpp"
 
@@ -40,13 +44,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvArgs a) 
   constexpr int NSB = 3;
   constexpr int WM = (BN == 128) ? 2 : 4, WN = 4 / WM;
   constexpr int WTM = BM / WM, WTN = BN / WN;
-  constexpr int MI = WTM / 32, NI = WTN / 32;
+  constexpr int MB = WTM / 16, NB = WTN / 16;          // 16x16 MFMA blocks per wave tile
   constexpr int C_PITCH = BN * 2 + 16;
   static_assert(HaloCfg<BN, TH, TW>::PATCH_BYTES == PATCH_BYTES && NSB == 3, "host/device LDS layout mismatch");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // HaloCfg::LDS_BYTES (> 64 KiB: dynamic)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r32 = lane & 31, h = lane >> 5;
+  const int l16 = lane & 15, c4 = lane >> 4;           // 16x16x32 operand map: row/col l16, k-chunk c4 (8 bf16 each)
   const int wm = wave / WN, wn = wave % WN;
   const int NT = a.Co / BN, TXN = a.Wo / TW, TYN = a.Ho / TH;     // tiles walk the OUTPUT grid (= input grid, x2 if `up`)
   int t = blockIdx.x;
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvArgs a) 
     const int py = q / PW, px = q - py * PW;
     const int yy = y0 - 1 + py, xx = x0 - 1 + px;          // on the logical (post-upsample) grid
     const bool ok = q < NPIX && (unsigned)yy < (unsigned)a.Hlog && (unsigned)xx < (unsigned)a.Wlog;
-    p_src[i] = ok ? in + ((size_t)(n * a.Hi + (yy >> a.up)) * a.Wi + (xx >> a.up)) * a.ldi + (slot ^ ((q >> 2) & 3)) * EPC
+    p_src[i] = ok ? in + ((size_t)(n * a.Hi + (yy >> a.up)) * a.Wi + (xx >> a.up)) * a.ldi + (slot ^ (((q >> 2) & 1) << 1)) * EPC
                   : nullptr;
   }
   const size_t wrow = (size_t)9 * a.Ci;
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvArgs a) 
 #pragma unroll
   for (int i = 0; i < B_IT; ++i) {
     const int row = (wave + 4 * i) * 16 + lrow;
-    b_src[i] = wk + (size_t)(n0 + row) * wrow + (slot ^ ((row >> 2) & 3)) * EPC;
+    b_src[i] = wk + (size_t)(n0 + row) * wrow + (slot ^ (((row >> 2) & 1) << 1)) * EPC;
   }
   unsigned char* const patch0 = lds;
   unsigned char* const bring = lds + 2 * PATCH_BYTES;
@@ -98,24 +102,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvArgs a) 
   };
 
   // ---- fragment geometry ------------------------------------------------------------------------
-  int q0[MI];                                        // patch pixel of (tile pixel, tap (0,0))
+  int q0[MB];                                        // patch pixel of (tile pixel, tap (0,0))
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    const int p = wm * WTM + mi * 32 + r32;
+  for (int mb = 0; mb < MB; ++mb) {
+    const int p = wm * WTM + mb * 16 + l16;
     const int py = p / TW, px = p - py * TW;
-    q0[mi] = py * PW + px;
+    q0[mb] = py * PW + px;
   }
-  int brow[NI];
+  int boff[NB];                                      // byte offset of this lane's fragment inside a weight slab
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) brow[ni] = wn * WTN + ni * 32 + r32;
+  for (int nb = 0; nb < NB; ++nb) {
+    const int row = wn * WTN + nb * 16 + l16;
+    boff[nb] = row * PIXB + ((c4 ^ (((row >> 2) & 1) << 1)) << 4);
+  }
 
-  f32x16 acc[MI][NI];
+  f32x4 acc[MB][NB];
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
+  for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nC = a.Ci / BK;
   const int S = nC * 9;
@@ -151,22 +156,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvArgs a) 
     const unsigned char* pb = bring + stage * B_BYTES;
     const int kh = tap / 3, kw = tap - kh * 3;
     const int toff = flip ? (2 - kh) * PW + (2 - kw) : kh * PW + kw;
+    {   // one 32-deep slab = one v_mfma_f32_16x16x32_bf16 per (pixel block, channel block)
+      bf16x8 bfr[NB];
 #pragma unroll
-    for (int kq = 0; kq < 2; ++kq) {
-      const int c = kq * 2 + h;
-      uint4 af[MI], bf[NI];
+      for (int nb = 0; nb < NB; ++nb) bfr[nb] = *reinterpret_cast<const bf16x8*>(pb + boff[nb]);
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        const int q = q0[mi] + toff;
-        af[mi] = *reinterpret_cast<const uint4*>(pa + q * PIXB + ((c ^ ((q >> 2) & 3)) << 4));
+      for (int mb = 0; mb < MB; ++mb) {
+        const int q = q0[mb] + toff;
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(pa + q * PIXB + ((c4 ^ (((q >> 2) & 1) << 1)) << 4));
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[nb], acc[mb][nb], 0, 0, 0);
       }
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-        bf[ni] = *reinterpret_cast<const uint4*>(pb + brow[ni] * PIXB + ((c ^ ((brow[ni] >> 2) & 3)) << 4));
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) Frag<T>::mma(af[mi], bf[ni], acc[mi][ni]);
     }
     // the next slab (and, in order before it, any older patch) must have landed; what may stay in
     // flight: the slab issued this step and a patch issued this step or the one before
@@ -186,38 +186,40 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvArgs a) 
 
   // ---- epilogue ------------------------------------------------------------------------------------
   T* __restrict__ out = reinterpret_cast<T*>(a.out);
-  float bcol[NI];
+  float bcol[NB];
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) bcol[ni] = a.bias ? a.bias[n0 + brow[ni]] : 0.f;
+  for (int nb = 0; nb < NB; ++nb) bcol[nb] = a.bias ? a.bias[n0 + wn * WTN + nb * 16 + l16] : 0.f;
   float* const red = reinterpret_cast<float*>(lds + HaloCfg<BN, TH, TW>::C_BYTES);      // [WM][2][BN] behind the C tile
   if (a.stats) {        // fused BatchNorm statistics of the ROUNDED outputs this tile stores
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
+    for (int nb = 0; nb < NB; ++nb) {
       float sm = 0.f, sq = 0.f;
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
+      for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = to_f32<T>(from_f32<T>(acc[mi][ni][r] + bcol[ni]));
+        for (int r = 0; r < 4; ++r) {
+          const float v = to_f32<T>(from_f32<T>(acc[mb][nb][r] + bcol[nb]));
           sm += v;
           sq += v * v;
         }
-      sm += __shfl_xor(sm, 32, 64);
-      sq += __shfl_xor(sq, 32, 64);
-      if (h == 0) {
-        red[(wm * 2 + 0) * BN + brow[ni]] = sm;
-        red[(wm * 2 + 1) * BN + brow[ni]] = sq;
+      sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);      // fold the four row groups (lane >> 4)
+      sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
+      if (c4 == 0) {
+        red[(wm * 2 + 0) * BN + wn * WTN + nb * 16 + l16] = sm;
+        red[(wm * 2 + 1) * BN + wn * WTN + nb * 16 + l16] = sq;
       }
     }
   }
+  // C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
+  for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        *reinterpret_cast<T*>(lds + row * C_PITCH + brow[ni] * 2) = from_f32<T>(acc[mi][ni][r] + bcol[ni]);
+      for (int r = 0; r < 4; ++r) {
+        const int row = wm * WTM + mb * 16 + c4 * 4 + r;
+        const int col = wn * WTN + nb * 16 + l16;
+        *reinterpret_cast<T*>(lds + row * C_PITCH + col * 2) = from_f32<T>(acc[mb][nb][r] + bcol[nb]);
       }
   __syncthreads();
   if (a.stats && tid < 2 * BN) {

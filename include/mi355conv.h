@@ -57,6 +57,10 @@ int mi355_pack_nchw(const float* x, void* y, int N, int C, int H, int W, int ld,
 int mi355_pack_conv_weight(const float* w, void* wf, void* wb, int Co, int Ci, int Cip, int KH, int KW,
                            int transposed, int dtype, mi355_stream_t s);
 
+/* Every weight pack of a launch plan in ONE launch: `table` = n descriptors of 8 int64 in device memory
+ * {w, wf, wb (0 = none), Co, Ci, Cip, KH*KW, transposed}, same semantics as mi355_pack_conv_weight. */
+int mi355_pack_conv_weights_batched(const int64_t* table, int n, int dtype, mi355_stream_t s);
+
 /* ---- implicit-GEMM convolution on MFMA -------------------------------------------------
  * out[m][j] (+)= bias[j] + sum_{kh,kw,c} in[src(m,kh,kw)][c] * wk[j][kh*KW+kw][c]
  *   m = (n,ho,wo);  t = o*mul + k*kmul + off (per axis);  valid iff t % div == 0 and

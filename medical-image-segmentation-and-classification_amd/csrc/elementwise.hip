@@ -120,6 +120,47 @@ extern "C" int mi355_pack_conv_weight(const float* w, void* wf, void* wb, int Co
   return MI355_OK;
 }
 
+// All weight packs of a plan in ONE launch: blockIdx.y selects the descriptor
+// {w, wf, wb, Co, Ci, Cip, taps, transposed} (8 x int64 each, device memory), blockIdx.x strides its elements.
+template <typename T>
+__global__ void pack_weight_batched_kernel(const long long* __restrict__ table) {
+  const long long* d = table + (size_t)blockIdx.y * 8;
+  const float* __restrict__ w = reinterpret_cast<const float*>(d[0]);
+  T* __restrict__ wf = reinterpret_cast<T*>(d[1]);
+  T* __restrict__ wb = reinterpret_cast<T*>(d[2]);
+  const int Co = (int)d[3], Ci = (int)d[4], Cip = (int)d[5], taps = (int)d[6], transposed = (int)d[7];
+  const long long total = (long long)Co * taps * Cip;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    {
+      const int ci = (int)(i % Cip);
+      const int tap = (int)((i / Cip) % taps);
+      const int co = (int)(i / ((long long)Cip * taps));
+      float v = 0.f;
+      if (ci < Ci) v = transposed ? w[((long long)ci * Co + co) * taps + tap] : w[((long long)co * Ci + ci) * taps + tap];
+      wf[i] = from_f32<T>(v);
+    }
+    if (wb) {
+      const int co = (int)(i % Co);
+      const int tap = (int)((i / Co) % taps);
+      const int ci = (int)(i / ((long long)Co * taps));
+      float v = 0.f;
+      if (ci < Ci) v = transposed ? w[((long long)ci * Co + co) * taps + tap] : w[((long long)co * Ci + ci) * taps + tap];
+      wb[i] = from_f32<T>(v);
+    }
+  }
+}
+
+extern "C" int mi355_pack_conv_weights_batched(const int64_t* table, int n, int dtype, mi355_stream_t s) {
+  MI355_CHECK_ARG(table && n > 0 && n <= 65535, "pack_conv_weights_batched: bad arguments");
+  dim3 grid(64, n);      // 64 x 256 threads stride each descriptor (largest pack: 1024*9*1024 elements)
+  if (dtype == MI355_BF16)
+    hipLaunchKernelGGL((pack_weight_batched_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)s, (const long long*)table);
+  else
+    hipLaunchKernelGGL((pack_weight_batched_kernel<float>), grid, dim3(256), 0, (hipStream_t)s, (const long long*)table);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
 // ---- max pooling -----------------------------------------------------------------------------------------
 template <typename T>
 __global__ void maxpool_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int N, int H, int W, int C,
@@ -236,12 +277,72 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ x, int ldx, const T* __
   }
 }
 
+// k = 2, stride = 2, pad = 0 (every U-Net / VGG pool): windows do not overlap, so one thread owns one pooled
+// pixel x 16-B chunk: reads the four inputs and dy once, writes the four gradients once.
+template <typename T>
+__global__ void maxpool2x2_bwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy, T* __restrict__ dx,
+                                      int lddx, int N, int H, int W, int C, int accumulate) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  const int cp = C / EPC, Ho = H / 2, Wo = W / 2;
+  const long long total = (long long)N * Ho * Wo * cp;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % cp) * EPC;
+    long long p = i / cp;
+    const int wo = (int)(p % Wo); p /= Wo;
+    const int ho = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    const size_t base = ((size_t)(n * H + 2 * ho) * W + 2 * wo);
+    Vec16<T> xv[4];
+    xv[0] = ld16<T>(x + base * ldx + c0);
+    xv[1] = ld16<T>(x + (base + 1) * ldx + c0);
+    xv[2] = ld16<T>(x + (base + W) * ldx + c0);
+    xv[3] = ld16<T>(x + (base + W + 1) * ldx + c0);
+    const Vec16<T> g = ld16<T>(dy + ((size_t)(n * Ho + ho) * Wo + wo) * lddy + c0);
+    int win[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {       // first maximum in scan order (torch's tie rule)
+      float m = to_f32<T>(xv[0].v[e]);
+      int w = 0;
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        const float v = to_f32<T>(xv[k].v[e]);
+        if (v > m) { m = v; w = k; }
+      }
+      win[e] = w;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      T* o = dx + (base + (k & 1) + (k >> 1) * W) * lddx + c0;
+      Vec16<T> ov;
+      if (accumulate) ov = ld16<T>(o);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        const float add = win[e] == k ? to_f32<T>(g.v[e]) : 0.f;
+        ov.v[e] = from_f32<T>(accumulate ? to_f32<T>(ov.v[e]) + add : add);
+      }
+      st16<T>(o, ov);
+    }
+  }
+}
+
 extern "C" int mi355_maxpool_bwd(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, int N, int H, int W,
                                  int C, int k, int stride, int pad, int accumulate, int dtype, mi355_stream_t s) {
   MI355_CHECK_ARG(x && dy && dx, "maxpool_bwd: null pointer");
   const int epc = dtype == MI355_BF16 ? 8 : 4;
   MI355_CHECK_ARG(C % epc == 0, "maxpool_bwd: C=%d must be a multiple of %d", C, epc);
   const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  if (k == 2 && stride == 2 && pad == 0 && H % 2 == 0 && W % 2 == 0) {
+    long long b2 = ((long long)N * Ho * Wo * (C / epc) + 255) / 256;
+    if (b2 > 8192) b2 = 8192;
+    if (dtype == MI355_BF16)
+      hipLaunchKernelGGL((maxpool2x2_bwd_kernel<bf16_t>), dim3((int)b2), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, ldx,
+                         (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, N, H, W, C, accumulate);
+    else
+      hipLaunchKernelGGL((maxpool2x2_bwd_kernel<float>), dim3((int)b2), dim3(256), 0, (hipStream_t)s, (const float*)x, ldx,
+                         (const float*)dy, lddy, (float*)dx, lddx, N, H, W, C, accumulate);
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+  }
   long long blocks = ((long long)N * H * W * (C / epc) + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   if (dtype == MI355_BF16)

@@ -133,6 +133,9 @@ class Plan:
             for a in l.args:
                 if isinstance(a, GRef):
                     self.last_write[id(a.param)] = i
+        self.zero_grad_params = list(b.zero_grad_params)   # biases in front of a train-mode BN: gradient == 0, never launched
+        for p in self.zero_grad_params:
+            self.last_write.setdefault(id(p), -1)
 
     # -- binding: resolve pointers once per stream --------------------------------------------
     def _resolve(self, launches: List[Launch], stream):
@@ -235,9 +238,11 @@ class Builder:
         self.keep = []
         self.ws_need = {"bytes": 0, "f32": 0}
         self._packs = {}
+        self._pack_table = []            # every weight pack of the plan goes into ONE batched launch
         self._grad_first = {}
         self.params_seen = []
         self.grad_params = []
+        self.zero_grad_params = []
         self.input = None
         self.output = None
         self.dout = None
@@ -380,7 +385,7 @@ class Builder:
             k = w.shape[2]
             wf = self._alloc(co * k * k * cip)
             wb = self._alloc(co * k * k * cip) if self.want_grad else None
-            self.pre.append(Launch("mi355_pack_conv_weight", w, wf, wb, co, ci, cip, k, k, 1 if transposed else 0, self.code))
+            self._pack_table.append((w, wf, wb, co, ci, cip, k * k, 1 if transposed else 0))
             self.see(w, conv.bias)
             self._packs[key] = (wf, wb)
         return self._packs[key]
@@ -526,14 +531,15 @@ class Builder:
                 dres = self.new_tensor(y.N, y.H, y.W, C)      # accumulate through a temporary
             else:
                 dres = self.grad_of(dres_to)
-        want_bias = bias is not None and bias.requires_grad
-        part1 = self.ws_f32(nb * 2 * C + nb * C) if want_bias else None
+        # The gradient of a conv bias that feeds a train-mode BatchNorm is exactly zero (sum_m dy = 0 because
+        # sum_m xhat = 0); torch computes ~1e-9 of round-off there.  It is not computed: the slot in the flat
+        # gradient buffer stays at its initial zero, the parameter is still registered as "has a gradient".
+        if bias is not None and bias.requires_grad and id(bias) not in self._grad_first:
+            self.pgrad(bias)
+            self.zero_grad_params.append(bias)
         self.bwd.append(Launch("mi355_bn_bwd_apply", da, da.ld, am, am.ld if am is not None else 0, y, y.ld, bn.weight,
-                               st["mean"], st["invstd"], st["scale"], st["shift"], sums, dy, dy.ld, dres, dres.ld if dres is not None else 0,
-                               (self._ws_off(part1, nb * 2 * C * 4) if want_bias else None), y.M, C, 1 if act else 0, self.code))
-        if want_bias:
-            ref, beta = self.pgrad(bias)
-            self.bwd.append(Launch("mi355_colsum_finalize", self._ws_off(part1, nb * 2 * C * 4), nb, 1, C, ref, beta))
+                               st["mean"], st["invstd"], st["scale"], st["shift"], sums, dy, dy.ld,
+                               dres, dres.ld if dres is not None else 0, None, y.M, C, 1 if act else 0, self.code))
         if dres is not None and dres is not dres_to._grad:
             rg = self.grad_of(dres_to)
             self.bwd.append(Launch("mi355_add", rg, rg.ld, dres, dres.ld, rg, rg.ld, y.M, C, self.code))
@@ -941,6 +947,12 @@ class Builder:
 
     # ---- finish -------------------------------------------------------------------------------------------------------------
     def finish(self):
+        if self._pack_table:
+            rows = [[w.data_ptr(), wf.data_ptr(), wb.data_ptr() if wb is not None else 0, co, ci, cip, taps, tr]
+                    for (w, wf, wb, co, ci, cip, taps, tr) in self._pack_table]
+            table = torch.tensor(rows, dtype=torch.int64).to(self.device)
+            self.keep.append(table)
+            self.pre.append(Launch("mi355_pack_conv_weights_batched", table, len(rows), self.code))
         for r in reversed(self._rules):
             r()
         # resolve _WsOff into (tensor, byte offset) late-bound pairs

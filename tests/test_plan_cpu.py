@@ -54,8 +54,11 @@ def test_plan_structure(name):
                 assert beta is not None, l.name
                 d = first if beta == 0.0 else later
                 d[id(a.param)] = d.get(id(a.param), 0) + 1
+    zero = {id(p) for p in plan.zero_grad_params}        # conv biases in front of a train-mode BN: gradient is exactly 0
+    names_of = {id(p): k for k, p in net.named_parameters()}
+    assert all(names_of[i].endswith(".bias") for i in zero)
     for p in params:
-        assert first.get(id(p), 0) >= 1, "parameter never written"
+        assert first.get(id(p), 0) >= 1 or id(p) in zero, "parameter never written"
     if name == "R2AttU_Net":
         assert sum(later.values()) > 0            # shared recurrent weights accumulate over 6 applications
     elif name == "ResNet18":

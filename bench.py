@@ -51,6 +51,9 @@ def make_batch(b, hw, seed, device):
     return x.to(device), m.to(device)
 
 
+SPLIT_BY_SHAPE = False
+
+
 def profile_plan(plan, x, stream, reps=2):
     """Instrumented replay: HIP events around every launch of the forward and backward plans."""
     # single-stream resolution on purpose: HIP events on this stream must bracket every kernel (the production
@@ -70,6 +73,8 @@ def profile_plan(plan, x, stream, reps=2):
         torch.cuda.synchronize()
         for l, e0, e1 in recs:
             key = l.tag or l.name
+            if SPLIT_BY_SHAPE and l.name in ("mi355_bn_act", "mi355_bn_bwd_reduce", "mi355_bn_bwd_apply"):
+                key = f"{l.name} M={l.args[-4]} C={l.args[-3]}"
             a = agg.setdefault(key, [0.0, 0, 0.0, 0.0])
             a[0] += e0.elapsed_time(e1)
             a[1] += 1
@@ -126,6 +131,8 @@ def main():
     ap.add_argument("--model", default="AttentionUNet")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--table-rows", type=int, default=25)
+    ap.add_argument("--split-by-shape", action="store_true", help="kernel table: one row per (launcher, M x C) of the BN kernels")
     ap.add_argument("--graph", type=int, default=0, help="capture the step into a hipGraph (1) or run eagerly (0)")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel time table to stderr")
     ap.add_argument("--force-dp", action="store_true", help="exercise the RCCL data-parallel path even with one rank")
@@ -232,15 +239,18 @@ def main():
     # ---- per-kernel roofline (instrumented replay of the same plan, rank 0) -----------------------------
     if rank == 0 and not args.no_profile:
         plan = [p for p in model.engine.plans.values() if p.training and p.dout is not None][0]
+        global SPLIT_BY_SHAPE
+        SPLIT_BY_SHAPE = args.split_by_shape
         agg = profile_plan(plan, x, torch.cuda.current_stream().cuda_stream)
         total = sum(v[0] for v in agg.values())
         ranked = sorted(agg.items(), key=lambda kv: -kv[1][0])
         if args.kernel_table:
-            print(f"{'kernel / launcher':58s} {'ms/step':>9s} {'launches':>8s} {'TFLOP/s':>9s} {'share':>6s}", file=sys.stderr)
+            print(f"{'kernel / launcher':58s} {'ms/step':>9s} {'launches':>8s} {'TFLOP/s':>9s} {'GB/s':>8s} {'share':>6s}", file=sys.stderr)
             reps = 2
-            for k, (ms_, n, fl, _) in ranked[:25]:
+            for k, (ms_, n, fl, nb_) in ranked[:args.table_rows]:
                 tf = fl / (ms_ * 1e-3) / 1e12 if fl else 0.0
-                print(f"{k:58s} {ms_ / reps:9.3f} {n // reps:8d} {tf:9.1f} {ms_ / total:6.1%}", file=sys.stderr)
+                gbs = nb_ / (ms_ * 1e-3) / 1e9 if nb_ else 0.0      # algorithmic bytes / time
+                print(f"{k:58s} {ms_ / reps:9.3f} {n // reps:8d} {tf:9.1f} {gbs:8.0f} {ms_ / total:6.1%}", file=sys.stderr)
             print(f"{'sum of plan launches':58s} {total / reps:9.3f}", file=sys.stderr)
         k, (ms_, n, fl, nb) = ranked[0]
         traffic, traffic_src = pmc_traffic(k)

@@ -121,38 +121,59 @@ extern "C" int mi355_pack_conv_weight(const float* w, void* wf, void* wb, int Co
 }
 
 // All weight packs of a plan in ONE launch: blockIdx.y selects the descriptor
-// {w, wf, wb, Co, Ci, Cip, taps, transposed} (8 x int64 each, device memory), blockIdx.x strides its elements.
+// {w, wf, wb, Co, Ci, Cip, taps, transposed} (8 x int64 each, device memory); blockIdx.x strides 32 x TB tiles of
+// the parameter's two outer dimensions (w[a][b][tap]: a = co, b = ci; ConvTranspose: a = ci, b = co).  A tile is
+// read with coalesced rows (TB*taps contiguous floats per a), parked in LDS, and written twice: once with b as
+// the inner dimension, once with a — both as contiguous 32-element runs.
 template <typename T>
-__global__ void pack_weight_batched_kernel(const long long* __restrict__ table) {
+__global__ __launch_bounds__(256) void pack_weight_batched_kernel(const long long* __restrict__ table) {
+  constexpr int TA = 32, ROWMAX = 288, PITCH = ROWMAX + 1;
+  __shared__ float tile[TA * PITCH];
   const long long* d = table + (size_t)blockIdx.y * 8;
   const float* __restrict__ w = reinterpret_cast<const float*>(d[0]);
   T* __restrict__ wf = reinterpret_cast<T*>(d[1]);
   T* __restrict__ wb = reinterpret_cast<T*>(d[2]);
   const int Co = (int)d[3], Ci = (int)d[4], Cip = (int)d[5], taps = (int)d[6], transposed = (int)d[7];
-  const long long total = (long long)Co * taps * Cip;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    {
-      const int ci = (int)(i % Cip);
-      const int tap = (int)((i / Cip) % taps);
-      const int co = (int)(i / ((long long)Cip * taps));
-      float v = 0.f;
-      if (ci < Ci) v = transposed ? w[((long long)ci * Co + co) * taps + tap] : w[((long long)co * Ci + ci) * taps + tap];
-      wf[i] = from_f32<T>(v);
+  const int A = transposed ? Ci : Co, B = transposed ? Co : Ci;          // extents present in w
+  const int Ap = transposed ? Cip : Co, Bp = transposed ? Co : Cip;      // extents of the packs (ci padded to Cip)
+  int TB = ROWMAX / taps;
+  TB = TB > 32 ? 32 : (TB < 1 ? 1 : TB);
+  if (taps > ROWMAX) return;                                             // guarded on the host
+  T* __restrict__ out_b = transposed ? wb : wf;     // [a][tap][b]  (b inner, extent Bp)
+  T* __restrict__ out_a = transposed ? wf : wb;     // [b][tap][a]  (a inner, extent Ap)
+  const int tilesB = (Bp + TB - 1) / TB, tiles = ((Ap + TA - 1) / TA) * tilesB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const int a0 = (t / tilesB) * TA, b0 = (t % tilesB) * TB;
+    const int nb = min(TB, Bp - b0), na = min(TA, Ap - a0), len = nb * taps;
+    const int nbv = max(0, min(nb, B - b0)) * taps;                      // elements of the row that exist in w
+    __syncthreads();
+    for (int r = wave; r < na; r += 4) {
+      const int a = a0 + r;
+      const float* src = w + ((size_t)a * B + b0) * taps;
+      for (int e = lane; e < len; e += 64) tile[r * PITCH + e] = (a < A && e < nbv) ? src[e] : 0.f;
     }
-    if (wb) {
-      const int co = (int)(i % Co);
-      const int tap = (int)((i / Co) % taps);
-      const int ci = (int)(i / ((long long)Co * taps));
-      float v = 0.f;
-      if (ci < Ci) v = transposed ? w[((long long)ci * Co + co) * taps + tap] : w[((long long)co * Ci + ci) * taps + tap];
-      wb[i] = from_f32<T>(v);
+    __syncthreads();
+    if (out_b) {
+      const int n = na * taps * nb;
+      for (int i = tid; i < n; i += 256) {
+        const int bb = i % nb, tap = (i / nb) % taps, r = i / (nb * taps);
+        out_b[((size_t)(a0 + r) * taps + tap) * Bp + b0 + bb] = from_f32<T>(tile[r * PITCH + bb * taps + tap]);
+      }
+    }
+    if (out_a) {
+      const int n = nb * taps * na;
+      for (int i = tid; i < n; i += 256) {
+        const int r = i % na, tap = (i / na) % taps, bb = i / (na * taps);
+        out_a[((size_t)(b0 + bb) * taps + tap) * Ap + a0 + r] = from_f32<T>(tile[r * PITCH + bb * taps + tap]);
+      }
     }
   }
 }
 
 extern "C" int mi355_pack_conv_weights_batched(const int64_t* table, int n, int dtype, mi355_stream_t s) {
   MI355_CHECK_ARG(table && n > 0 && n <= 65535, "pack_conv_weights_batched: bad arguments");
-  dim3 grid(64, n);      // 64 x 256 threads stride each descriptor (largest pack: 1024*9*1024 elements)
+  dim3 grid(256, n);     // 256 workgroups stride the tiles of each descriptor (largest: 1024 x 512 x 9 = 512 tiles)
   if (dtype == MI355_BF16)
     hipLaunchKernelGGL((pack_weight_batched_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)s, (const long long*)table);
   else

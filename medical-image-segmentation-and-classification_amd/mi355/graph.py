@@ -385,6 +385,7 @@ class Builder:
             k = w.shape[2]
             wf = self._alloc(co * k * k * cip)
             wb = self._alloc(co * k * k * cip) if self.want_grad else None
+            assert k * k <= 288, "batched weight pack: at most 288 taps"
             self._pack_table.append((w, wf, wb, co, ci, cip, k * k, 1 if transposed else 0))
             self.see(w, conv.bias)
             self._packs[key] = (wf, wb)
@@ -516,7 +517,8 @@ class Builder:
         # added in front of the ReLU (residual / second operand), in which case the activated tensor is read
         am = a if (act and dres_to is not None) else None
         self.bwd.append(Launch("mi355_bn_bwd_reduce", da, da.ld, am, am.ld if am is not None else 0, y, y.ld,
-                               st["mean"], st["invstd"], st["scale"], st["shift"], part, y.M, C, 1 if act else 0, self.code))
+                               st["mean"], st["invstd"], st["scale"], st["shift"], part, y.M, C, 1 if act else 0, self.code,
+                               nbytes=(2 + (am is not None)) * y.M * C * self.esz))
         sums = self.f32(2 * C)
         need_pg = bn.weight.requires_grad
         if need_pg:
@@ -539,7 +541,8 @@ class Builder:
             self.zero_grad_params.append(bias)
         self.bwd.append(Launch("mi355_bn_bwd_apply", da, da.ld, am, am.ld if am is not None else 0, y, y.ld, bn.weight,
                                st["mean"], st["invstd"], st["scale"], st["shift"], sums, dy, dy.ld,
-                               dres, dres.ld if dres is not None else 0, None, y.M, C, 1 if act else 0, self.code))
+                               dres, dres.ld if dres is not None else 0, None, y.M, C, 1 if act else 0, self.code,
+                               nbytes=(3 + (am is not None) + (dres is not None)) * y.M * C * self.esz))
         if dres is not None and dres is not dres_to._grad:
             rg = self.grad_of(dres_to)
             self.bwd.append(Launch("mi355_add", rg, rg.ld, dres, dres.ld, rg, rg.ld, y.M, C, self.code))
@@ -565,7 +568,8 @@ class Builder:
         r = res if res is not None else post_add
         flags = (1 if act else 0) | (2 if post_add is not None else 0)
         self.fwd.append(Launch("mi355_bn_act", y, y.ld, st["scale"], st["shift"], None, 0, None, None,
-                               r, r.ld if r is not None else 0, a, a.ld, y.M, y.C, flags, self.code))
+                               r, r.ld if r is not None else 0, a, a.ld, y.M, y.C, flags, self.code,
+                               nbytes=(2 + (r is not None)) * y.M * y.C * self.esz))
         a.needs_grad = y.needs_grad or bn.weight.requires_grad or (r is not None and r.needs_grad)
 
         def rule():

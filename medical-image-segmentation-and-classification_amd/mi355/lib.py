@@ -17,7 +17,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(os.path.dirname(_HERE))
 HEADER = os.path.join(REPO_ROOT, "include", "mi355conv.h")
-SO_PATH = os.path.join(_HERE, "libmi355conv.so")
+SO_PATH = os.environ.get("MI355_LIB") or os.path.join(_HERE, "libmi355conv.so")   # MI355_LIB: A/B another build
 
 F32, BF16 = 0, 1
 DTYPE_CODE = {torch.float32: F32, torch.bfloat16: BF16}

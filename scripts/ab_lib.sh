@@ -1,9 +1,9 @@
 #!/bin/bash
-# A/B two builds of libmi355conv.so on the same box: $1 = alternative .so (in mi355/), $2 = kernel tag regex; interleaved rounds
-M=medical-image-segmentation-and-classification_amd/mi355
-cp $M/libmi355conv.so /tmp/base.so
-for tag in base alt base alt; do
-  if [ $tag = alt ]; then cp $M/$1 $M/libmi355conv.so; else cp /tmp/base.so $M/libmi355conv.so; fi
-  python scripts/conv_layers.py 2>/dev/null | awk -v t=$tag -v pat="$2" '$0 ~ pat {ms+=$(NF-1)} END {printf "%s total ms %.3f\n", t, ms}'
+# A/B builds of libmi355conv.so on the same box: ab_lib.sh "<kernel tag regex>" ab/A.so ab/B.so ...  (two interleaved rounds;
+# MI355_LIB selects the library, see mi355/lib.py)
+pat="$1"; shift
+for round in 1 2; do
+  for so in "$@"; do
+    MI355_LIB=$PWD/$so python scripts/conv_layers.py 2>/dev/null | awk -v t=$so -v pat="$pat" '$0 ~ pat {ms+=$(NF-1)} END {printf "%-28s total ms %.3f\n", t, ms}'
+  done
 done
-cp /tmp/base.so $M/libmi355conv.so

@@ -14,7 +14,8 @@ for _ in range(2):
     out = m(x); crit(out, y).backward()
 torch.cuda.synchronize()
 plan = [p for p in m.engine.plans.values() if p.dout is not None][0]
-fwd, bwd = plan.bind(torch.cuda.current_stream().cuda_stream)
+_s = torch.cuda.current_stream().cuda_stream
+fwd, bwd = plan._resolve(plan.pre + plan.fwd, _s), plan._resolve(plan.bwd, _s)   # single stream: events must bracket the side-stream launches too
 rows = {}
 for rep in range(3):
     recs = []

@@ -33,6 +33,17 @@ void mi355_set_error(const char* fmt, ...);
     if (e__ != hipSuccess) MI355_FAIL((int)e__, "launch failed: %s", hipGetErrorString(e__)); \
   } while (0)
 
+// ---- XCD-aware tile order ------------------------------------------------------------------
+// Workgroups are dealt to the 8 XCDs round-robin (workgroup b -> XCD b % 8, each with a private L2).  Tiles that
+// are neighbours in the logical order share operand panels (the same input patch under different channel tiles,
+// the same pixel rows under different weight tiles), so every XCD gets ONE CONTIGUOUS RANGE of the logical order
+// and the shared panels meet in one L2 instead of being fetched from HBM by up to eight.  Bijective for any n.
+__device__ __forceinline__ int xcd_tile(int b, int n) {
+  const int q = n >> 3, r = n & 7;           // XCD k owns q + (k < r) tiles, starting at k*q + min(k, r)
+  const int k = b & 7;
+  return k * q + (k < r ? k : r) + (b >> 3);
+}
+
 // ---- scalar conversions ------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }

@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvArgs a) 
   const int l16 = lane & 15, c4 = lane >> 4;           // 16x16x32 operand map: row/col l16, k-chunk c4 (8 bf16 each)
   const int wm = wave / WN, wn = wave % WN;
   const int NT = a.Co / BN, TXN = a.Wo / TW, TYN = a.Ho / TH;     // tiles walk the OUTPUT grid (= input grid, x2 if `up`)
-  int t = blockIdx.x;
+  const int bid = xcd_tile(blockIdx.x, gridDim.x);
+  int t = bid;
   const int nt = t % NT; t /= NT;
   const int tx = t % TXN; t /= TXN;
   const int ty = t % TYN;
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvArgs a) 
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < WM; ++w) v += red[(w * 2 + q) * BN + c];
-    a.stats[((size_t)(blockIdx.x / NT) * 2 + q) * a.Co + n0 + c] = v;
+    a.stats[((size_t)(bid / NT) * 2 + q) * a.Co + n0 + c] = v;
   }
   constexpr int CPRC = BN / EPC;
   for (int id = tid; id < BM * CPRC; id += 256) {

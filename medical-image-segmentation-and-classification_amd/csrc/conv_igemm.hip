@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   const int r32 = lane & 31, h = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
   const int NT = a.Co / BN;
-  const int mt = blockIdx.x / NT, nt = blockIdx.x - mt * NT;
+  const int bid = xcd_tile(blockIdx.x, gridDim.x);
+  const int mt = bid / NT, nt = bid - mt * NT;
   const int m0 = mt * BM, n0 = nt * BN;
   const T* __restrict__ in = reinterpret_cast<const T*>(a.in);
   const T* __restrict__ wk = reinterpret_cast<const T*>(a.wk);
@@ -292,7 +293,8 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvArgs a) {
   const int r32 = lane & 31, h = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
   const int NT = a.Co / BN;
-  const int mt = blockIdx.x / NT, nt = blockIdx.x - mt * NT;
+  const int bid = xcd_tile(blockIdx.x, gridDim.x);
+  const int mt = bid / NT, nt = bid - mt * NT;
   const int m0 = mt * BM, n0 = nt * BN;
   const T* __restrict__ in = reinterpret_cast<const T*>(a.in);
   const T* __restrict__ wk = reinterpret_cast<const T*>(a.wk);

@@ -48,9 +48,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   const int r32 = lane & 31, h = lane >> 5;
   const int wo_ = wave >> 1, wi_ = wave & 1;
   const int ciTiles = (a.Ci + BCI - 1) / BCI;
-  const int co0 = (blockIdx.x / ciTiles) * BCO, ci0 = (blockIdx.x % ciTiles) * BCI;
-  const int tap = blockIdx.y, kh = tap / a.KW, kw = tap - kh * a.KW;
-  const int split = blockIdx.z;
+  // logical order: (tile, tap) fastest inside a split — those blocks read the same pixel rows
+  int bid = xcd_tile((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z);
+  const int bx = bid % gridDim.x; bid /= gridDim.x;
+  const int co0 = (bx / ciTiles) * BCO, ci0 = (bx % ciTiles) * BCI;
+  const int tap = bid % gridDim.y, kh = tap / a.KW, kw = tap - kh * a.KW;
+  const int split = bid / gridDim.y;
   const int p_begin = split * a.chunk;
   const int p_end = min(a.M, p_begin + a.chunk);
   const T* __restrict__ x = reinterpret_cast<const T*>(a.x);

@@ -45,7 +45,10 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args 
   const int h = lane >> 5, r32 = lane & 31;
   const int qo = wave >> 1, qi = wave & 1;
   const int ciTiles = (a.Ci + 63) / 64;
-  const int co0 = (blockIdx.x / ciTiles) * 64, ci0 = (blockIdx.x % ciTiles) * 64;
+  // logical order: the (co, ci) tiles of one split are neighbours — they stream the same pixel rows
+  const int bid = xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+  const int bx = bid % gridDim.x, by = bid / gridDim.x;
+  const int co0 = (bx / ciTiles) * 64, ci0 = (bx % ciTiles) * 64;
   const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
   const T* __restrict__ dy = reinterpret_cast<const T*>(a.dy);
   const char* zero = reinterpret_cast<const char*>(g_zero_page);
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args 
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(row_img + px * 128 + chunk * 16 + (col & 7) * 2));
   };
 
-  const int item0 = blockIdx.y * a.items_per_block;
+  const int item0 = by * a.items_per_block;
   const int item1 = min(a.items, item0 + a.items_per_block);
   for (int item = item0; item < item1; ++item) {
     int t = item;
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args 
     __builtin_amdgcn_s_barrier();                  // the next item's DMA overwrites the slots read last
   }
 
-  float* __restrict__ ws = a.ws + (size_t)blockIdx.y * a.Co * 9 * a.Ci;
+  float* __restrict__ ws = a.ws + (size_t)by * a.Co * 9 * a.Ci;
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll

@@ -29,7 +29,7 @@ for p in (ROOT, PKG):
 import torch
 import torch.distributed as dist
 
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}     # dense MFMA peaks, MI355X_MICROARCH.md
 FWD_GFLOP_PER_IMG = 132.850                       # AttentionUNet 256x256 forward
 TRAIN_GFLOP_PER_IMG = 398.32                      # 3x forward minus the first layer's dgrad
 
@@ -127,7 +127,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--model", default="AttentionUNet")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -161,7 +161,7 @@ def main():
     torch.manual_seed(0)
     model = get_seg_model({"AttentionUNet": "attentionunet", "R2AttU_Net": "r2attunet", "R2U_Net": "r2unet",
                            "ResNetUnet": "resnetunet"}[args.model])
-    model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model.compute_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
     model = model.to(device).train()
     model.engine._check_storage()
     dp = DataParallel(model, force=args.force_dp) if use_dp else None

@@ -14,9 +14,9 @@
  *     channel stride `ld` lives at ((n*H+h)*W+w)*ld + c, so a channel slice of a
  *     wider (concatenated) tensor is addressed with the same pointer arithmetic;
  *   - `dtype` selects the storage/MFMA input type of activations and packed
- *     weights (MI355_F32: v_mfma_f32_32x32x2_f32, MI355_BF16:
- *     v_mfma_f32_32x32x16_bf16); accumulation, statistics, parameters and
- *     parameter gradients are always fp32;
+ *     weights (MI355_F32: v_mfma_f32_32x32x2_f32, MI355_BF16 / MI355_F16:
+ *     v_mfma_f32_{32x32x16,16x16x32}_{bf16,f16}); accumulation, statistics,
+ *     parameters and parameter gradients are always fp32;
  *   - every launcher takes the hipStream_t to enqueue on and returns 0 or a
  *     negative MI355_ERR_* / positive hipError_t; mi355_last_error() gives text.
  */
@@ -31,7 +31,7 @@ extern "C" {
 
 typedef struct ihipStream_t* mi355_stream_t; /* == hipStream_t */
 
-enum { MI355_F32 = 0, MI355_BF16 = 1 };
+enum { MI355_F32 = 0, MI355_BF16 = 1, MI355_F16 = 2 };
 enum { MI355_OK = 0, MI355_ERR_ARG = -1, MI355_ERR_UNSUPPORTED = -2 };
 
 int mi355_version(void);
@@ -211,15 +211,22 @@ int mi355_ce_smooth(const float* z, const int64_t* y, float* loss, float* dz, co
 /* ---- optimiser on flat fp32 buffers (utils/helpers.py:251,304,332-336) ---------------------- */
 /* sumsq partials of a flat gradient buffer; nblocks = mi355_rowreduce_blocks(n). */
 int mi355_sumsq_partial(const float* g, float* partial, long long n, mi355_stream_t s);
-/* norm[0] = sqrt(sum partial); coef[0] = min(1, max_norm/(norm+1e-6)) (clip_grad_norm_);
- * found_inf[0] = 1 if the norm is not finite; otherwise step[0] += 1 (the optimiser step counter). */
-int mi355_clip_coef(const float* partial, int nblocks, float max_norm, float inv_scale, float* norm,
-                    float* coef, float* found_inf, int32_t* step, mi355_stream_t s);
-/* AdamW, decoupled decay; g is multiplied by coef[0]*inv_scale first; skipped when found_inf[0] != 0.
- * step_count is read from device memory (graph-capturable). */
+/* norm[0] = sqrt(sum partial) * inv_scale * (dev_scale ? dev_scale[0] : 1); coef[0] = min(1, max_norm/(norm+1e-6))
+ * (clip_grad_norm_); found_inf[0] = 1 if the norm is not finite; otherwise step[0] += 1 (the optimiser step counter).
+ * dev_scale: optional device-side factor — the loss scaler's 1/scale (GradScaler.unscale_, helpers.py:329). */
+int mi355_clip_coef(const float* partial, int nblocks, float max_norm, float inv_scale, const float* dev_scale,
+                    float* norm, float* coef, float* found_inf, int32_t* step, mi355_stream_t s);
+/* AdamW, decoupled decay; g is multiplied by coef[0]*inv_scale*(dev_scale ? dev_scale[0] : 1) first; skipped when
+ * found_inf[0] != 0 (GradScaler.step).  step_count is read from device memory (graph-capturable). */
 int mi355_adamw(float* p, const float* g, float* m, float* v, long long n, const float* lr, float beta1,
-                float beta2, float eps, float wd, const float* coef, float inv_scale, const float* found_inf,
-                const int32_t* step, mi355_stream_t s);
+                float beta2, float eps, float wd, const float* coef, float inv_scale, const float* dev_scale,
+                const float* found_inf, const int32_t* step, mi355_stream_t s);
+/* step[0] += 1 unless found_inf[0] != 0 (found_inf may be NULL). */
+int mi355_step_tick(int32_t* step, const float* found_inf, mi355_stream_t s);
+/* torch.amp.GradScaler.update() (helpers.py:285,336) on device state: found_inf -> scale *= backoff, tracker = 0;
+ * otherwise ++tracker == interval -> scale *= growth, tracker = 0;  inv_scale = 1/scale. */
+int mi355_amp_update(float* scale, float* inv_scale, int32_t* growth_tracker, const float* found_inf, float growth,
+                     float backoff, int interval, mi355_stream_t s);
 int mi355_fill_f32(float* p, float v, long long n, mi355_stream_t s);
 
 /* ---- segmentation metrics counters (utils/tester.py:92-193; helpers.py:223-227) ------------- */

@@ -61,12 +61,11 @@ extern "C" int mi355_rowreduce_blocks(long long M) { return rowreduce_blocks(M);
 
 extern "C" int mi355_bn_stats(const void* x, float* partial, long long M, int C, int ld, int dtype, mi355_stream_t s) {
   MI355_CHECK_ARG(x && partial && M > 0, "bn_stats: bad arguments");
-  if (dtype == MI355_BF16) {
-    BnStatsOp<bf16_t> op{(const bf16_t*)x, ld};
-    return rowred_launch<bf16_t>(op, M, C, partial, (hipStream_t)s);
-  }
-  BnStatsOp<float> op{(const float*)x, ld};
-  return rowred_launch<float>(op, M, C, partial, (hipStream_t)s);
+  return dispatch_dtype(dtype, "bn_stats", [&](auto tag) {
+    using T = decltype(tag);
+    BnStatsOp<T> op{(const T*)x, ld};
+    return rowred_launch<T>(op, M, C, partial, (hipStream_t)s);
+  });
 }
 
 template <int CH, int BL>
@@ -182,14 +181,11 @@ extern "C" int mi355_bn_act(const void* x, int ldx, const float* scale, const fl
                             long long M, int C, int act, int dtype, mi355_stream_t s) {
   MI355_CHECK_ARG(x && y && M > 0, "bn_act: bad arguments");
   MI355_CHECK_ARG(!x2 || (scale2 && shift2), "bn_act: second operand needs scale2/shift2");
-  if (dtype == MI355_BF16) {
-    BnActOp<bf16_t> op{(const bf16_t*)x, ldx, scale, shift, (const bf16_t*)x2, ldx2, scale2, shift2,
-                       (const bf16_t*)res, ldr, (bf16_t*)y, ldy, act};
-    return rowmap_launch<bf16_t>(op, M, C, (hipStream_t)s);
-  }
-  BnActOp<float> op{(const float*)x, ldx, scale, shift, (const float*)x2, ldx2, scale2, shift2,
-                    (const float*)res, ldr, (float*)y, ldy, act};
-  return rowmap_launch<float>(op, M, C, (hipStream_t)s);
+  return dispatch_dtype(dtype, "bn_act", [&](auto tag) {
+    using T = decltype(tag);
+    BnActOp<T> op{(const T*)x, ldx, scale, shift, (const T*)x2, ldx2, scale2, shift2, (const T*)res, ldr, (T*)y, ldy, act};
+    return rowmap_launch<T>(op, M, C, (hipStream_t)s);
+  });
 }
 
 // ---- backward ------------------------------------------------------------------------------------
@@ -232,12 +228,11 @@ extern "C" int mi355_bn_bwd_reduce(const void* dy, int lddy, const void* y, int 
                                    const float* mean, const float* invstd, const float* mscale, const float* mshift,
                                    float* partial, long long M, int C, int act, int dtype, mi355_stream_t s) {
   MI355_CHECK_ARG(dy && x && mean && invstd && partial && (!act || y || (mscale && mshift)), "bn_bwd_reduce: null pointer");
-  if (dtype == MI355_BF16) {
-    BnBwdReduceOp<bf16_t> op{(const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, (const bf16_t*)x, ldx, mean, invstd, mscale, mshift, act};
-    return rowred_launch<bf16_t>(op, M, C, partial, (hipStream_t)s);
-  }
-  BnBwdReduceOp<float> op{(const float*)dy, lddy, (const float*)y, ldy, (const float*)x, ldx, mean, invstd, mscale, mshift, act};
-  return rowred_launch<float>(op, M, C, partial, (hipStream_t)s);
+  return dispatch_dtype(dtype, "bn_bwd_reduce", [&](auto tag) {
+    using T = decltype(tag);
+    BnBwdReduceOp<T> op{(const T*)dy, lddy, (const T*)y, ldy, (const T*)x, ldx, mean, invstd, mscale, mshift, act};
+    return rowred_launch<T>(op, M, C, partial, (hipStream_t)s);
+  });
 }
 
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, float* __restrict__ sums,
@@ -314,14 +309,12 @@ extern "C" int mi355_bn_bwd_apply(const void* dy, int lddy, const void* y, int l
                                   float* dbias_partial, long long M, int C, int act, int dtype, mi355_stream_t s) {
   MI355_CHECK_ARG(dy && x && gamma && mean && invstd && sums && dx && (!act || y || (mscale && mshift)), "bn_bwd_apply: null pointer");
   const float invM = (float)(1.0 / (double)M);
-  if (dtype == MI355_BF16) {
-    BnBwdApplyOp<bf16_t> op{(const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, (const bf16_t*)x, ldx, gamma, mean, invstd,
-                            mscale, mshift, sums, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, invM, C, act};
-    return rowred_launch<bf16_t>(op, M, C, dbias_partial, (hipStream_t)s);
-  }
-  BnBwdApplyOp<float> op{(const float*)dy, lddy, (const float*)y, ldy, (const float*)x, ldx, gamma, mean, invstd, mscale, mshift, sums,
-                         (float*)dx, lddx, (float*)dres, lddres, invM, C, act};
-  return rowred_launch<float>(op, M, C, dbias_partial, (hipStream_t)s);
+  return dispatch_dtype(dtype, "bn_bwd_apply", [&](auto tag) {
+    using T = decltype(tag);
+    BnBwdApplyOp<T> op{(const T*)dy, lddy, (const T*)y, ldy, (const T*)x, ldx, gamma, mean, invstd,
+                       mscale, mshift, sums, (T*)dx, lddx, (T*)dres, lddres, invM, C, act};
+    return rowred_launch<T>(op, M, C, dbias_partial, (hipStream_t)s);
+  });
 }
 
 // ---- plain column sums (bias gradients) -------------------------------------------------------------
@@ -340,12 +333,11 @@ template <typename T> struct ColSumOp {
 
 extern "C" int mi355_colsum(const void* x, int ld, float* partial, long long M, int C, int dtype, mi355_stream_t s) {
   MI355_CHECK_ARG(x && partial, "colsum: null pointer");
-  if (dtype == MI355_BF16) {
-    ColSumOp<bf16_t> op{(const bf16_t*)x, ld};
-    return rowred_launch<bf16_t>(op, M, C, partial, (hipStream_t)s);
-  }
-  ColSumOp<float> op{(const float*)x, ld};
-  return rowred_launch<float>(op, M, C, partial, (hipStream_t)s);
+  return dispatch_dtype(dtype, "colsum", [&](auto tag) {
+    using T = decltype(tag);
+    ColSumOp<T> op{(const T*)x, ld};
+    return rowred_launch<T>(op, M, C, partial, (hipStream_t)s);
+  });
 }
 
 __global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nblocks, int stride, int C,

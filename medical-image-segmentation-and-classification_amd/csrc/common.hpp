@@ -8,7 +8,9 @@
 #include "../../include/mi355conv.h"
 
 typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -48,9 +50,11 @@ __device__ __forceinline__ int xcd_tile(int b, int n) {
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+template <> __device__ __forceinline__ float to_f32<f16_t>(f16_t v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return (f16_t)v; }
 
 // 16-byte vector of T (4 x f32 or 8 x bf16)
 template <typename T> struct Vec16;
@@ -62,6 +66,26 @@ template <> struct Vec16<bf16_t> {
   static constexpr int N = 8;
   bf16_t v[8];
 };
+template <> struct Vec16<f16_t> {
+  static constexpr int N = 8;
+  f16_t v[8];
+};
+
+// ---- 2-byte MFMA by element type (fragments travel as raw 16-byte vectors typed bf16x8) ---------------------
+template <typename T> __device__ __forceinline__ f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c);
+template <> __device__ __forceinline__ f32x16 mfma_32x32x16<bf16_t>(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x16 mfma_32x32x16<f16_t>(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <typename T> __device__ __forceinline__ f32x4 mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c);
+template <> __device__ __forceinline__ f32x4 mfma_16x16x32<bf16_t>(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4 mfma_16x16x32<f16_t>(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
 
 template <typename T> __device__ __forceinline__ Vec16<T> ld16(const T* p) {
   Vec16<T> r;
@@ -85,3 +109,14 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 
 static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- dtype dispatch of the launchers: f(T{}) with T = float / bf16_t / f16_t ------------------------------
+template <typename F> static inline int dispatch_dtype(int dtype, const char* who, F&& f) {
+  switch (dtype) {
+    case MI355_F32: return f(float{});
+    case MI355_BF16: return f(bf16_t{});
+    case MI355_F16: return f(f16_t{});
+    default: MI355_FAIL(MI355_ERR_UNSUPPORTED, "%s: unknown dtype %d", who, dtype);
+  }
+}
+static inline bool dtype_is_2byte(int dtype) { return dtype == MI355_BF16 || dtype == MI355_F16; }

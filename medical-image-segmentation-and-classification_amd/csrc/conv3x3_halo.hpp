@@ -9,7 +9,7 @@
 // MFMA drops ~3x versus the im2col-style gather, DMA-issue and address VALU per MFMA ~3x.
 //   (nearest x2 up-sampling of the input is folded into the patch gather: source pixel = logical >> 1)
 // (s_setprio(1) around the MFMA cluster was measured: -3 % with two 4-wave workgroups per CU — not used.)
-//   MFMA        : v_mfma_f32_16x16x32_bf16 — one instruction consumes a whole 32-deep slab of a 16x16 block;
+//   MFMA        : v_mfma_f32_16x16x32_bf16 / _f16 — one instruction consumes a whole 32-deep slab of a 16x16 block;
 //                 at equal operand traffic it ran 8 % faster in situ than 32x32x16 (the chip holds a higher
 //                 clock on this shape, MI355X_MICROARCH.md DVFS item 7)
 //   patch image : pixel-linear, 64 B per pixel, 16-B chunk slot = chunk ^ (((pixel >> 2) & 1) << 1)
@@ -29,9 +29,9 @@ template <int BN, int TH, int TW> struct HaloCfg {
   static constexpr int LDS_BYTES = RING > EPI_BYTES ? RING : EPI_BYTES;
 };
 
-template <int BN, int TH, int TW>
+template <typename T, int BN, int TH, int TW>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvArgs a) {
-  typedef bf16_t T;
+  static_assert(sizeof(T) == 2, "bf16 / fp16 only");
   constexpr int BK = 32, EPC = 8, BM = TH * TW;
   static_assert(BM == 256, "tile must hold 256 pixels");
   constexpr int PH = TH + 2, PW = TW + 2, NPIX = PH * PW;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvArgs a) 
         const int q = q0[mb] + toff;
         const bf16x8 af = *reinterpret_cast<const bf16x8*>(pa + q * PIXB + ((c4 ^ (((q >> 2) & 1) << 1)) << 4));
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[nb], acc[mb][nb], 0, 0, 0);
+        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = mfma_16x16x32<T>(af, bfr[nb], acc[mb][nb]);
       }
     }
     // the next slab (and, in order before it, any older patch) must have landed; what may stay in
@@ -245,18 +245,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvArgs a) 
   }
 }
 
-template <int BN, int TH, int TW>
+template <typename T, int BN, int TH, int TW>
 static int launch_halo(const ConvArgs& a, hipStream_t s) {
   const int grid = a.N * (a.Ho / TH) * (a.Wo / TW) * (a.Co / BN);
   constexpr int lds_bytes = HaloCfg<BN, TH, TW>::LDS_BYTES;
   static bool configured = false;        // immutable after the first call (set before any launch of this variant)
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BN, TH, TW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, BN, TH, TW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        lds_bytes);
     if (e != hipSuccess) MI355_FAIL((int)e, "conv3x3_halo: cannot reserve %d B of LDS: %s", lds_bytes, hipGetErrorString(e));
     configured = true;
   }
-  hipLaunchKernelGGL((conv3x3_halo_kernel<BN, TH, TW>), dim3(grid), dim3(256), lds_bytes, s, a);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<T, BN, TH, TW>), dim3(grid), dim3(256), lds_bytes, s, a);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }

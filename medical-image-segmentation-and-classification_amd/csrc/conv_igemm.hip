@@ -36,6 +36,11 @@ template <> struct Frag<bf16_t> {
                                                 0, 0);
   }
 };
+template <> struct Frag<f16_t> {
+  static __device__ __forceinline__ void mma(const uint4& a, const uint4& b, f32x16& c) {
+    c = mfma_32x32x16<f16_t>(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c);
+  }
+};
 template <> struct Frag<float> {
   static __device__ __forceinline__ void mma(const uint4& a, const uint4& b, f32x16& c) {
     const f32x4 av = __builtin_bit_cast(f32x4, a), bv = __builtin_bit_cast(f32x4, b);
@@ -265,9 +270,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 // ==============================================================================================
 #include "dma.hpp"
 
-template <int BN, int BK, int NS>
+template <typename T, int BN, int BK, int NS>
 __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvArgs a) {
-  typedef bf16_t T;
+  static_assert(sizeof(T) == 2, "bf16 / fp16 only");
   constexpr int BM = 128;
   constexpr int EPC = 8;
   constexpr int CPR = BK / EPC;               // 16-B chunks per LDS row (4 or 8)
@@ -487,10 +492,10 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvArgs a) {
   }
 }
 
-template <int BN, int BK, int NS>
+template <typename T, int BN, int BK, int NS>
 static int launch_dma(const ConvArgs& a, hipStream_t s) {
   const int grid = ceil_div(a.M, 128) * (a.Co / BN);
-  hipLaunchKernelGGL((conv_igemm_dma_kernel<BN, BK, NS>), dim3(grid), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((conv_igemm_dma_kernel<T, BN, BK, NS>), dim3(grid), dim3(256), 0, s, a);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }
@@ -517,7 +522,7 @@ enum IgemmVariant { IG_GENERIC = 0, IG_DMA, IG_HALO_8x32, IG_HALO_16x16 };
 // ONE place that decides which kernel serves a shape (also used by the statistics-row query).
 static IgemmVariant pick_variant(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int mul, int kmul, int off,
                                  int div, int up, int dtype) {
-  if (dtype != MI355_BF16) return IG_GENERIC;
+  if (!dtype_is_2byte(dtype)) return IG_GENERIC;
   static const int force_generic = getenv("MI355_IGEMM_VARIANT") ? atoi(getenv("MI355_IGEMM_VARIANT")) == 0 : 0;
   if (force_generic) return IG_GENERIC;
   const int Hlog = up ? 2 * Hi : Hi, Wlog = up ? 2 * Wi : Wi;
@@ -552,13 +557,12 @@ extern "C" int mi355_conv2d_igemm(const void* in, const void* wk, const float* b
   MI355_CHECK_ARG(ldi >= Ci && ldo >= Co, "conv2d_igemm: channel stride smaller than channel count");
   MI355_CHECK_ARG((long long)N * Ho * Wo < (1ll << 31) && (long long)N * Hi * Wi < (1ll << 31),
                   "conv2d_igemm: pixel count overflows int32");
-  MI355_CHECK_ARG(dtype == MI355_BF16 || dtype == MI355_F32, "conv2d_igemm: unknown dtype %d", dtype);
-  const int esz = dtype == MI355_BF16 ? 2 : 4;
+  MI355_CHECK_ARG(dtype == MI355_BF16 || dtype == MI355_F16 || dtype == MI355_F32, "conv2d_igemm: unknown dtype %d", dtype);
+  const int esz = dtype_is_2byte(dtype) ? 2 : 4;
   MI355_CHECK_ARG(((uintptr_t)in % 16) == 0 && ((uintptr_t)wk % 16) == 0 && ((uintptr_t)out % 16) == 0 &&
                       (ldi * esz) % 16 == 0 && (ldo * esz) % 16 == 0,
                   "conv2d_igemm: pointers / channel strides must be 16-byte aligned");
-  MI355_CHECK_ARG(Ci % (dtype == MI355_BF16 ? 32 : 16) == 0, "conv2d_igemm: Ci=%d must be a multiple of %d", Ci,
-                  dtype == MI355_BF16 ? 32 : 16);
+  MI355_CHECK_ARG(Ci % (esz == 2 ? 32 : 16) == 0, "conv2d_igemm: Ci=%d must be a multiple of %d", Ci, esz == 2 ? 32 : 16);
   const IgemmVariant v = pick_variant(Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up, dtype);
   MI355_CHECK_ARG(!stats || (v != IG_GENERIC && !accumulate),
                   "conv2d_igemm: fused statistics are not available for this shape/dtype (mi355_conv2d_igemm_stat_rows == 0)");
@@ -577,17 +581,22 @@ extern "C" int mi355_conv2d_igemm(const void* in, const void* wk, const float* b
   a.Wlog = up ? 2 * Wi : Wi;
   hipStream_t st = (hipStream_t)s;
   const bool k64 = Ci % 64 == 0;
-  switch (v) {
-    case IG_HALO_8x32: return Co % 128 == 0 ? launch_halo<128, 8, 32>(a, st) : launch_halo<64, 8, 32>(a, st);
-    case IG_HALO_16x16: return Co % 128 == 0 ? launch_halo<128, 16, 16>(a, st) : launch_halo<64, 16, 16>(a, st);
-    case IG_DMA:
-      // measured on MI355X (AttentionUNet shapes): the 2-deep BK=64 ring (2 workgroups/CU) wins for 128-wide tiles,
-      // the 3-deep BK=32 ring (3-4 workgroups/CU) for 64-wide tiles and for Ci % 64 != 0
-      if (Co % 128 == 0) return k64 ? launch_dma<128, 64, 2>(a, st) : launch_dma<128, 32, 3>(a, st);
-      if (Co % 64 == 0) return launch_dma<64, 32, 3>(a, st);
-      return launch_dma<32, 64, 3>(a, st);
-    default:
-      if (dtype == MI355_BF16) return k64 ? launch_bn<bf16_t, 64>(a, st) : launch_bn<bf16_t, 32>(a, st);
-      return launch_bn<float, 16>(a, st);
-  }
+  if (esz == 4) return launch_bn<float, 16>(a, st);
+  return dispatch_dtype(dtype, "conv2d_igemm", [&](auto tag) -> int {
+    using T = decltype(tag);
+    if constexpr (sizeof(T) == 2) {
+      switch (v) {
+        case IG_HALO_8x32: return Co % 128 == 0 ? launch_halo<T, 128, 8, 32>(a, st) : launch_halo<T, 64, 8, 32>(a, st);
+        case IG_HALO_16x16: return Co % 128 == 0 ? launch_halo<T, 128, 16, 16>(a, st) : launch_halo<T, 64, 16, 16>(a, st);
+        case IG_DMA:
+          // measured on MI355X (AttentionUNet shapes): the 2-deep BK=64 ring (2 workgroups/CU) wins for 128-wide tiles,
+          // the 3-deep BK=32 ring (3-4 workgroups/CU) for 64-wide tiles and for Ci % 64 != 0
+          if (Co % 128 == 0) return k64 ? launch_dma<T, 128, 64, 2>(a, st) : launch_dma<T, 128, 32, 3>(a, st);
+          if (Co % 64 == 0) return launch_dma<T, 64, 32, 3>(a, st);
+          return launch_dma<T, 32, 64, 3>(a, st);
+        default: return k64 ? launch_bn<T, 64>(a, st) : launch_bn<T, 32>(a, st);
+      }
+    }
+    return MI355_ERR_UNSUPPORTED;
+  });
 }

@@ -26,6 +26,9 @@ struct WgradArgs {
 };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+// MFMA element type of the 2-byte branch (the fp32 instantiation never executes it, but must compile)
+template <typename T> struct TwoByte { typedef T type; };
+template <> struct TwoByte<float> { typedef bf16_t type; };
 
 template <typename T, int BCO, int BCI>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = mfma_32x32x16<typename TwoByte<T>::type>(af[mi], bfr[ni], acc[mi][ni]);
       }
     } else {
 #pragma unroll 4
@@ -263,7 +266,7 @@ extern "C" int mi355_conv2d_wgrad(const void* x, const void* dy, float* ws, int 
                                   int dtype, mi355_stream_t s) {
   MI355_CHECK_ARG(x && dy && ws, "conv2d_wgrad: null pointer");
   MI355_CHECK_ARG(splits >= 1 && splits <= 65535, "conv2d_wgrad: splits=%d out of range", splits);
-  const int esz = dtype == MI355_BF16 ? 2 : 4;
+  const int esz = dtype_is_2byte(dtype) ? 2 : 4;
   const int epc = 16 / esz;
   MI355_CHECK_ARG(Ci % epc == 0 && Co % epc == 0, "conv2d_wgrad: Ci=%d / Co=%d must be multiples of %d", Ci, Co, epc);
   MI355_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && (ldx * esz) % 16 == 0 && (ldy * esz) % 16 == 0,
@@ -280,7 +283,7 @@ extern "C" int mi355_conv2d_wgrad(const void* x, const void* dy, float* ws, int 
   a.Wlog = up ? 2 * Wi : Wi;
   a.chunk = ceil_div(ceil_div(a.M, splits), 32) * 32;
   static const int use_halo = getenv("MI355_WGRAD_HALO") ? atoi(getenv("MI355_WGRAD_HALO")) : 1;
-  if (dtype == MI355_BF16 && use_halo && stride == 1 && pad == 1 && halo_wgrad_shape(Ho, Wo, KH, KW) && Ho == a.Hlog && Wo == a.Wlog) {
+  if (dtype_is_2byte(dtype) && use_halo && stride == 1 && pad == 1 && halo_wgrad_shape(Ho, Wo, KH, KW) && Ho == a.Hlog && Wo == a.Wlog) {
     Wgrad3Args h;
     h.x = x; h.dy = dy; h.ws = ws;
     h.N = N; h.Hi = Hi; h.Wi = Wi; h.Ci = Ci; h.ldx = ldx;
@@ -289,13 +292,12 @@ extern "C" int mi355_conv2d_wgrad(const void* x, const void* dy, float* ws, int 
     h.items = N * (Wo / 32) * (Ho / h.RB);
     h.items_per_block = ceil_div(h.items, splits);
     dim3 grid(ceil_div(Co, 64) * ceil_div(Ci, 64), splits);
-    hipLaunchKernelGGL(wgrad3x3_halo_kernel, grid, dim3(256), 0, (hipStream_t)s, h);
+    if (dtype == MI355_F16) hipLaunchKernelGGL(wgrad3x3_halo_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)s, h);
+    else hipLaunchKernelGGL(wgrad3x3_halo_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, h);
     MI355_LAUNCH_CHECK();
     return MI355_OK;
   }
-  if (dtype == MI355_BF16) return wgrad_launch<bf16_t>(a, splits, (hipStream_t)s);
-  if (dtype == MI355_F32) return wgrad_launch<float>(a, splits, (hipStream_t)s);
-  MI355_FAIL(MI355_ERR_UNSUPPORTED, "conv2d_wgrad: unknown dtype %d", dtype);
+  return dispatch_dtype(dtype, "conv2d_wgrad", [&](auto tag) { return wgrad_launch<decltype(tag)>(a, splits, (hipStream_t)s); });
 }
 
 // dw[co][ci][kh][kw] (or [ci][co][kh][kw] when transposed) = beta*dw + sum_s ws[s][co][tap][ci]

@@ -38,15 +38,17 @@ static int pack_nchw_launch(const float* x, void* y, int N, int C, int H, int W,
 extern "C" int mi355_pack_input_nchw(const float* x, void* y, int N, int C, int H, int W, int Cpad, int dtype,
                                      mi355_stream_t s) {
   MI355_CHECK_ARG(x && y && Cpad >= C && Cpad % 8 == 0, "pack_input_nchw: bad arguments (C=%d Cpad=%d)", C, Cpad);
-  if (dtype == MI355_BF16) return pack_nchw_launch<bf16_t>(x, y, N, C, H, W, Cpad, Cpad, (hipStream_t)s);
-  return pack_nchw_launch<float>(x, y, N, C, H, W, Cpad, Cpad, (hipStream_t)s);
+  return dispatch_dtype(dtype, "pack_input_nchw", [&](auto tag) {
+    return pack_nchw_launch<decltype(tag)>(x, y, N, C, H, W, Cpad, Cpad, (hipStream_t)s);
+  });
 }
 
 extern "C" int mi355_pack_nchw(const float* x, void* y, int N, int C, int H, int W, int ld, int dtype, mi355_stream_t s) {
-  const int epc = dtype == MI355_BF16 ? 8 : 4;
+  const int epc = dtype_is_2byte(dtype) ? 8 : 4;
   MI355_CHECK_ARG(x && y && C % epc == 0 && ld >= C, "pack_nchw: C=%d must be a multiple of %d", C, epc);
-  if (dtype == MI355_BF16) return pack_nchw_launch<bf16_t>(x, y, N, C, H, W, ld, C, (hipStream_t)s);
-  return pack_nchw_launch<float>(x, y, N, C, H, W, ld, C, (hipStream_t)s);
+  return dispatch_dtype(dtype, "pack_nchw", [&](auto tag) {
+    return pack_nchw_launch<decltype(tag)>(x, y, N, C, H, W, ld, C, (hipStream_t)s);
+  });
 }
 
 template <typename T>
@@ -68,14 +70,12 @@ extern "C" int mi355_unpack_output_nchw(const void* x, float* y, int N, int C, i
   const long long HW = (long long)H * W, NHW = HW * N;
   long long blocks = (NHW * C + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  if (dtype == MI355_BF16)
-    hipLaunchKernelGGL((unpack_nchw_kernel<bf16_t>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, y, C, HW,
-                       NHW, ld);
-  else
-    hipLaunchKernelGGL((unpack_nchw_kernel<float>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const float*)x, y, C, HW,
-                       NHW, ld);
-  MI355_LAUNCH_CHECK();
-  return MI355_OK;
+  return dispatch_dtype(dtype, "unpack_nchw_kernel", [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((unpack_nchw_kernel<T>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const T*)x, y, C, HW, NHW, ld);
+    MI355_LAUNCH_CHECK();
+    return (int)MI355_OK;
+  });
 }
 
 // ---- weight packing ------------------------------------------------------------------------------------
@@ -110,14 +110,12 @@ extern "C" int mi355_pack_conv_weight(const float* w, void* wf, void* wb, int Co
   const long long total = (long long)Co * KH * KW * Cip;
   long long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  if (dtype == MI355_BF16)
-    hipLaunchKernelGGL((pack_weight_kernel<bf16_t>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, w, (bf16_t*)wf, (bf16_t*)wb,
-                       Co, Ci, Cip, KH * KW, transposed);
-  else
-    hipLaunchKernelGGL((pack_weight_kernel<float>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, w, (float*)wf, (float*)wb, Co,
-                       Ci, Cip, KH * KW, transposed);
-  MI355_LAUNCH_CHECK();
-  return MI355_OK;
+  return dispatch_dtype(dtype, "pack_weight_kernel", [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((pack_weight_kernel<T>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, w, (T*)wf, (T*)wb, Co, Ci, Cip, KH * KW, transposed);
+    MI355_LAUNCH_CHECK();
+    return (int)MI355_OK;
+  });
 }
 
 // All weight packs of a plan in ONE launch: blockIdx.y selects the descriptor
@@ -174,12 +172,12 @@ __global__ __launch_bounds__(256) void pack_weight_batched_kernel(const long lon
 extern "C" int mi355_pack_conv_weights_batched(const int64_t* table, int n, int dtype, mi355_stream_t s) {
   MI355_CHECK_ARG(table && n > 0 && n <= 65535, "pack_conv_weights_batched: bad arguments");
   dim3 grid(256, n);     // 256 workgroups stride the tiles of each descriptor (largest: 1024 x 512 x 9 = 512 tiles)
-  if (dtype == MI355_BF16)
-    hipLaunchKernelGGL((pack_weight_batched_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)s, (const long long*)table);
-  else
-    hipLaunchKernelGGL((pack_weight_batched_kernel<float>), grid, dim3(256), 0, (hipStream_t)s, (const long long*)table);
-  MI355_LAUNCH_CHECK();
-  return MI355_OK;
+  return dispatch_dtype(dtype, "pack_weight_batched_kernel", [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((pack_weight_batched_kernel<T>), grid, dim3(256), 0, (hipStream_t)s, (const long long*)table);
+    MI355_LAUNCH_CHECK();
+    return (int)MI355_OK;
+  });
 }
 
 // ---- max pooling -----------------------------------------------------------------------------------------
@@ -219,19 +217,17 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, int ldx, T* __restri
 extern "C" int mi355_maxpool_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, int k, int stride,
                                  int pad, int dtype, mi355_stream_t s) {
   MI355_CHECK_ARG(x && y, "maxpool_fwd: null pointer");
-  const int epc = dtype == MI355_BF16 ? 8 : 4;
+  const int epc = dtype_is_2byte(dtype) ? 8 : 4;
   MI355_CHECK_ARG(C % epc == 0, "maxpool_fwd: C=%d must be a multiple of %d", C, epc);
   const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
   long long blocks = ((long long)N * Ho * Wo * (C / epc) + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  if (dtype == MI355_BF16)
-    hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, ldx,
-                       (bf16_t*)y, ldy, N, H, W, C, Ho, Wo, k, stride, pad);
-  else
-    hipLaunchKernelGGL((maxpool_fwd_kernel<float>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const float*)x, ldx,
-                       (float*)y, ldy, N, H, W, C, Ho, Wo, k, stride, pad);
-  MI355_LAUNCH_CHECK();
-  return MI355_OK;
+  return dispatch_dtype(dtype, "maxpool_fwd_kernel", [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx, (T*)y, ldy, N, H, W, C, Ho, Wo, k, stride, pad);
+    MI355_LAUNCH_CHECK();
+    return (int)MI355_OK;
+  });
 }
 
 // Backward as a gather over input pixels (no atomics): input pixel (h,w) receives dy of every window
@@ -349,31 +345,27 @@ __global__ void maxpool2x2_bwd_kernel(const T* __restrict__ x, int ldx, const T*
 extern "C" int mi355_maxpool_bwd(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, int N, int H, int W,
                                  int C, int k, int stride, int pad, int accumulate, int dtype, mi355_stream_t s) {
   MI355_CHECK_ARG(x && dy && dx, "maxpool_bwd: null pointer");
-  const int epc = dtype == MI355_BF16 ? 8 : 4;
+  const int epc = dtype_is_2byte(dtype) ? 8 : 4;
   MI355_CHECK_ARG(C % epc == 0, "maxpool_bwd: C=%d must be a multiple of %d", C, epc);
   const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
   if (k == 2 && stride == 2 && pad == 0 && H % 2 == 0 && W % 2 == 0) {
     long long b2 = ((long long)N * Ho * Wo * (C / epc) + 255) / 256;
     if (b2 > 8192) b2 = 8192;
-    if (dtype == MI355_BF16)
-      hipLaunchKernelGGL((maxpool2x2_bwd_kernel<bf16_t>), dim3((int)b2), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, ldx,
-                         (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, N, H, W, C, accumulate);
-    else
-      hipLaunchKernelGGL((maxpool2x2_bwd_kernel<float>), dim3((int)b2), dim3(256), 0, (hipStream_t)s, (const float*)x, ldx,
-                         (const float*)dy, lddy, (float*)dx, lddx, N, H, W, C, accumulate);
-    MI355_LAUNCH_CHECK();
-    return MI355_OK;
+    return dispatch_dtype(dtype, "maxpool2x2_bwd_kernel", [&](auto tag) {
+      using T = decltype(tag);
+      hipLaunchKernelGGL((maxpool2x2_bwd_kernel<T>), dim3((int)b2), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx, (const T*)dy, lddy, (T*)dx, lddx, N, H, W, C, accumulate);
+      MI355_LAUNCH_CHECK();
+      return (int)MI355_OK;
+    });
   }
   long long blocks = ((long long)N * H * W * (C / epc) + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  if (dtype == MI355_BF16)
-    hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, ldx,
-                       (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, N, H, W, C, Ho, Wo, k, stride, pad, accumulate);
-  else
-    hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const float*)x, ldx,
-                       (const float*)dy, lddy, (float*)dx, lddx, N, H, W, C, Ho, Wo, k, stride, pad, accumulate);
-  MI355_LAUNCH_CHECK();
-  return MI355_OK;
+  return dispatch_dtype(dtype, "maxpool_bwd_kernel", [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx, (const T*)dy, lddy, (T*)dx, lddx, N, H, W, C, Ho, Wo, k, stride, pad, accumulate);
+    MI355_LAUNCH_CHECK();
+    return (int)MI355_OK;
+  });
 }
 
 // ---- nearest x2 upsample gradient ----------------------------------------------------------------------
@@ -417,18 +409,16 @@ __global__ void upsample2_bwd_kernel(const T* __restrict__ dy, int lddy, T* __re
 extern "C" int mi355_upsample2_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int H, int W, int C,
                                    int accumulate, int dtype, mi355_stream_t s) {
   MI355_CHECK_ARG(dy && dx, "upsample2_bwd: null pointer");
-  const int epc = dtype == MI355_BF16 ? 8 : 4;
+  const int epc = dtype_is_2byte(dtype) ? 8 : 4;
   MI355_CHECK_ARG(C % epc == 0, "upsample2_bwd: C=%d must be a multiple of %d", C, epc);
   long long blocks = ((long long)N * H * W * (C / epc) + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  if (dtype == MI355_BF16)
-    hipLaunchKernelGGL((upsample2_bwd_kernel<bf16_t>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const bf16_t*)dy, lddy,
-                       (bf16_t*)dx, lddx, N, H, W, C, accumulate);
-  else
-    hipLaunchKernelGGL((upsample2_bwd_kernel<float>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const float*)dy, lddy,
-                       (float*)dx, lddx, N, H, W, C, accumulate);
-  MI355_LAUNCH_CHECK();
-  return MI355_OK;
+  return dispatch_dtype(dtype, "upsample2_bwd_kernel", [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((upsample2_bwd_kernel<T>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const T*)dy, lddy, (T*)dx, lddx, N, H, W, C, accumulate);
+    MI355_LAUNCH_CHECK();
+    return (int)MI355_OK;
+  });
 }
 
 // ---- add / relu ----------------------------------------------------------------------------------------
@@ -450,12 +440,11 @@ template <typename T> struct AddOp {
 extern "C" int mi355_add(const void* a, int lda, const void* b, int ldb, void* y, int ldy, long long M, int C, int dtype,
                          mi355_stream_t s) {
   MI355_CHECK_ARG(a && y, "add: null pointer");
-  if (dtype == MI355_BF16) {
-    AddOp<bf16_t> op{(const bf16_t*)a, lda, (const bf16_t*)b, ldb, (bf16_t*)y, ldy};
-    return rowmap_launch<bf16_t>(op, M, C, (hipStream_t)s);
-  }
-  AddOp<float> op{(const float*)a, lda, (const float*)b, ldb, (float*)y, ldy};
-  return rowmap_launch<float>(op, M, C, (hipStream_t)s);
+  return dispatch_dtype(dtype, "add", [&](auto tag) {
+    using T = decltype(tag);
+    AddOp<T> op{(const T*)a, lda, (const T*)b, ldb, (T*)y, ldy};
+    return rowmap_launch<T>(op, M, C, (hipStream_t)s);
+  });
 }
 
 template <typename T> struct ReluOp {
@@ -479,21 +468,19 @@ template <typename T> struct ReluOp {
 
 extern "C" int mi355_relu_fwd(const void* x, int ldx, void* y, int ldy, long long M, int C, int dtype, mi355_stream_t s) {
   MI355_CHECK_ARG(x && y, "relu_fwd: null pointer");
-  if (dtype == MI355_BF16) {
-    ReluOp<bf16_t> op{nullptr, 0, (const bf16_t*)x, ldx, (bf16_t*)y, ldy};
-    return rowmap_launch<bf16_t>(op, M, C, (hipStream_t)s);
-  }
-  ReluOp<float> op{nullptr, 0, (const float*)x, ldx, (float*)y, ldy};
-  return rowmap_launch<float>(op, M, C, (hipStream_t)s);
+  return dispatch_dtype(dtype, "relu_fwd", [&](auto tag) {
+    using T = decltype(tag);
+    ReluOp<T> op{nullptr, 0, (const T*)x, ldx, (T*)y, ldy};
+    return rowmap_launch<T>(op, M, C, (hipStream_t)s);
+  });
 }
 
 extern "C" int mi355_relu_bwd(const void* dy, int lddy, const void* y, int ldy, void* dx, int lddx, long long M, int C,
                               int dtype, mi355_stream_t s) {
   MI355_CHECK_ARG(dy && y && dx, "relu_bwd: null pointer");
-  if (dtype == MI355_BF16) {
-    ReluOp<bf16_t> op{(const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, (bf16_t*)dx, lddx};
-    return rowmap_launch<bf16_t>(op, M, C, (hipStream_t)s);
-  }
-  ReluOp<float> op{(const float*)dy, lddy, (const float*)y, ldy, (float*)dx, lddx};
-  return rowmap_launch<float>(op, M, C, (hipStream_t)s);
+  return dispatch_dtype(dtype, "relu_bwd", [&](auto tag) {
+    using T = decltype(tag);
+    ReluOp<T> op{(const T*)dy, lddy, (const T*)y, ldy, (T*)dx, lddx};
+    return rowmap_launch<T>(op, M, C, (hipStream_t)s);
+  });
 }

@@ -82,19 +82,18 @@ __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const T* __restrict__ x
 extern "C" int mi355_rowdot_fwd(const void* x, int ldx, const float* w, const float* b, float* z, float* partial,
                                 long long M, int C, int dtype, mi355_stream_t s) {
   MI355_CHECK_ARG(x && w && z, "rowdot_fwd: null pointer");
-  const int epc = dtype == MI355_BF16 ? 8 : 4;
+  const int epc = dtype_is_2byte(dtype) ? 8 : 4;
   MI355_CHECK_ARG(C % epc == 0 && C / epc <= 64 * ROWDOT_MAXCH, "rowdot_fwd: unsupported C=%d", C);
   const int nb = rowreduce_blocks(M);
   const int rpb = (int)((M + nb - 1) / nb);
   const int tpr = pow2_tpr(C / epc);
-  if (dtype == MI355_BF16)
-    hipLaunchKernelGGL((rowdot_fwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, ldx, w, b, z, partial,
-                       M, C, rpb, tpr);
-  else
-    hipLaunchKernelGGL((rowdot_fwd_kernel<float>), dim3(nb), dim3(256), 0, (hipStream_t)s, (const float*)x, ldx, w, b, z, partial, M,
-                       C, rpb, tpr);
-  MI355_LAUNCH_CHECK();
-  return MI355_OK;
+  return dispatch_dtype(dtype, "rowdot_fwd", [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((rowdot_fwd_kernel<T>), dim3(nb), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx, w, b, z, partial, M, C, rpb,
+                       tpr);
+    MI355_LAUNCH_CHECK();
+    return (int)MI355_OK;
+  });
 }
 
 // dx[m][c] = dz[m]*w[c]*(mask ? x[m][c] > 0 : 1);  partial: q0 = sum_m dz[m]*x[m][c], q1 = sum_m dz[m]
@@ -126,12 +125,11 @@ template <typename T> struct RowdotBwdOp {
 extern "C" int mi355_rowdot_bwd(const float* dz, const void* x, int ldx, const float* w, void* dx, int lddx,
                                 float* partial, long long M, int C, int relu_mask, int dtype, mi355_stream_t s) {
   MI355_CHECK_ARG(dz && x && w && partial, "rowdot_bwd: null pointer");
-  if (dtype == MI355_BF16) {
-    RowdotBwdOp<bf16_t> op{dz, (const bf16_t*)x, ldx, w, (bf16_t*)dx, lddx, relu_mask};
-    return rowred_launch<bf16_t>(op, M, C, partial, (hipStream_t)s);
-  }
-  RowdotBwdOp<float> op{dz, (const float*)x, ldx, w, (float*)dx, lddx, relu_mask};
-  return rowred_launch<float>(op, M, C, partial, (hipStream_t)s);
+  return dispatch_dtype(dtype, "rowdot_bwd", [&](auto tag) {
+    using T = decltype(tag);
+    RowdotBwdOp<T> op{dz, (const T*)x, ldx, w, (T*)dx, lddx, relu_mask};
+    return rowred_launch<T>(op, M, C, partial, (hipStream_t)s);
+  });
 }
 
 // ---- x * sigmoid(bn1(z)) ---------------------------------------------------------------------------------
@@ -151,12 +149,11 @@ template <typename T> struct GateMulOp {
 extern "C" int mi355_gate_mul_fwd(const void* x, int ldx, const float* z, const float* scale, const float* shift, void* y,
                                   int ldy, long long M, int C, int dtype, mi355_stream_t s) {
   MI355_CHECK_ARG(x && z && scale && shift && y, "gate_mul_fwd: null pointer");
-  if (dtype == MI355_BF16) {
-    GateMulOp<bf16_t> op{(const bf16_t*)x, ldx, z, scale, shift, (bf16_t*)y, ldy};
-    return rowmap_launch<bf16_t>(op, M, C, (hipStream_t)s);
-  }
-  GateMulOp<float> op{(const float*)x, ldx, z, scale, shift, (float*)y, ldy};
-  return rowmap_launch<float>(op, M, C, (hipStream_t)s);
+  return dispatch_dtype(dtype, "gate_mul_fwd", [&](auto tag) {
+    using T = decltype(tag);
+    GateMulOp<T> op{(const T*)x, ldx, z, scale, shift, (T*)y, ldy};
+    return rowmap_launch<T>(op, M, C, (hipStream_t)s);
+  });
 }
 
 template <typename T>
@@ -213,20 +210,18 @@ extern "C" int mi355_gate_mul_bwd(const void* dy, int lddy, const void* x, int l
                                   int accumulate, float* dzn, float* partial, long long M, int C, int dtype,
                                   mi355_stream_t s) {
   MI355_CHECK_ARG(dy && x && z && scale && shift && mean && invstd && dx && dzn && partial, "gate_mul_bwd: null pointer");
-  const int epc = dtype == MI355_BF16 ? 8 : 4;
+  const int epc = dtype_is_2byte(dtype) ? 8 : 4;
   MI355_CHECK_ARG(C % epc == 0, "gate_mul_bwd: C=%d must be a multiple of %d", C, epc);
   const int nb = rowreduce_blocks(M);
   const int rpb = (int)((M + nb - 1) / nb);
   const int tpr = pow2_tpr(C / epc);
-  if (dtype == MI355_BF16)
-    hipLaunchKernelGGL((gate_mul_bwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, (hipStream_t)s, (const bf16_t*)dy, lddy,
-                       (const bf16_t*)x, ldx, z, scale, shift, mean, invstd, (bf16_t*)dx, lddx, accumulate, dzn, partial, M, C, rpb,
-                       tpr);
-  else
-    hipLaunchKernelGGL((gate_mul_bwd_kernel<float>), dim3(nb), dim3(256), 0, (hipStream_t)s, (const float*)dy, lddy, (const float*)x,
-                       ldx, z, scale, shift, mean, invstd, (float*)dx, lddx, accumulate, dzn, partial, M, C, rpb, tpr);
-  MI355_LAUNCH_CHECK();
-  return MI355_OK;
+  return dispatch_dtype(dtype, "gate_mul_bwd", [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((gate_mul_bwd_kernel<T>), dim3(nb), dim3(256), 0, (hipStream_t)s, (const T*)dy, lddy, (const T*)x, ldx, z, scale,
+                       shift, mean, invstd, (T*)dx, lddx, accumulate, dzn, partial, M, C, rpb, tpr);
+    MI355_LAUNCH_CHECK();
+    return (int)MI355_OK;
+  });
 }
 
 __global__ void bn1_bwd_apply_kernel(const float* __restrict__ dzn, const float* __restrict__ z, const float* gamma,

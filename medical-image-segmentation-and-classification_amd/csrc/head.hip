@@ -46,14 +46,12 @@ extern "C" int mi355_global_pool_fwd(const void* x, int ldx, float* y, int32_t* 
                                      int dtype, mi355_stream_t s) {
   MI355_CHECK_ARG(x && y && (!is_max || argmax), "global_pool_fwd: null pointer");
   dim3 grid(ceil_div(C, 64), N);
-  if (dtype == MI355_BF16)
-    hipLaunchKernelGGL((global_pool_fwd_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, ldx, y, argmax, HW, C,
-                       is_max);
-  else
-    hipLaunchKernelGGL((global_pool_fwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)s, (const float*)x, ldx, y, argmax, HW, C,
-                       is_max);
-  MI355_LAUNCH_CHECK();
-  return MI355_OK;
+  return dispatch_dtype(dtype, "global_pool_fwd_kernel", [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((global_pool_fwd_kernel<T>), grid, dim3(256), 0, (hipStream_t)s, (const T*)x, ldx, y, argmax, HW, C, is_max);
+    MI355_LAUNCH_CHECK();
+    return (int)MI355_OK;
+  });
 }
 
 template <typename T>
@@ -76,14 +74,12 @@ extern "C" int mi355_global_pool_bwd(const float* dy, const int32_t* argmax, voi
   const long long total = (long long)N * HW * C;
   long long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  if (dtype == MI355_BF16)
-    hipLaunchKernelGGL((global_pool_bwd_kernel<bf16_t>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, dy, argmax, (bf16_t*)dx,
-                       lddx, HW, C, is_max, total);
-  else
-    hipLaunchKernelGGL((global_pool_bwd_kernel<float>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, dy, argmax, (float*)dx, lddx,
-                       HW, C, is_max, total);
-  MI355_LAUNCH_CHECK();
-  return MI355_OK;
+  return dispatch_dtype(dtype, "global_pool_bwd_kernel", [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((global_pool_bwd_kernel<T>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, dy, argmax, (T*)dx, lddx, HW, C, is_max, total);
+    MI355_LAUNCH_CHECK();
+    return (int)MI355_OK;
+  });
 }
 
 // ---- Linear (fp32): one wave per output element -------------------------------------------------------

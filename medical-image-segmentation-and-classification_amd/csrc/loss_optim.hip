@@ -104,12 +104,12 @@ extern "C" int mi355_sumsq_partial(const float* g, float* partial, long long n, 
 }
 
 __global__ void clip_coef_kernel(const float* __restrict__ partial, int nblocks, float max_norm, float inv_scale,
-                                 float* norm, float* coef, float* found_inf, int32_t* step) {
+                                 const float* dev_scale, float* norm, float* coef, float* found_inf, int32_t* step) {
   double acc = 0;
   for (int b = threadIdx.x; b < nblocks; b += 64) acc += (double)partial[b];
   acc = wave_sum_d(acc);
   if (threadIdx.x == 0) {
-    const float nrm = (float)sqrt(acc) * inv_scale;
+    const float nrm = (float)sqrt(acc) * inv_scale * (dev_scale ? dev_scale[0] : 1.f);
     const bool bad = !isfinite(nrm);
     norm[0] = nrm;
     coef[0] = max_norm > 0.f ? fminf(1.f, max_norm / (nrm + 1e-6f)) : 1.f;
@@ -118,11 +118,11 @@ __global__ void clip_coef_kernel(const float* __restrict__ partial, int nblocks,
   }
 }
 
-extern "C" int mi355_clip_coef(const float* partial, int nblocks, float max_norm, float inv_scale, float* norm,
-                               float* coef, float* found_inf, int32_t* step, mi355_stream_t s) {
+extern "C" int mi355_clip_coef(const float* partial, int nblocks, float max_norm, float inv_scale, const float* dev_scale,
+                               float* norm, float* coef, float* found_inf, int32_t* step, mi355_stream_t s) {
   MI355_CHECK_ARG(partial && norm && coef, "clip_coef: null pointer");
-  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, partial, nblocks, max_norm, inv_scale, norm, coef,
-                     found_inf, step);
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, partial, nblocks, max_norm, inv_scale, dev_scale, norm,
+                     coef, found_inf, step);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }
@@ -132,10 +132,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float* __restrict__ v, long long n, const float* __restrict__ lr_p,
                                                     float beta1, float beta2, float eps, float wd,
                                                     const float* __restrict__ coef, float inv_scale,
+                                                    const float* __restrict__ dev_scale,
                                                     const float* __restrict__ found_inf, const int32_t* __restrict__ step) {
   if (found_inf && found_inf[0] != 0.f) return;
   const float lr = lr_p[0];
-  const float gs = (coef ? coef[0] : 1.f) * inv_scale;
+  const float gs = (coef ? coef[0] : 1.f) * inv_scale * (dev_scale ? dev_scale[0] : 1.f);
   const float t = (float)step[0];
   const float bc1 = 1.f - powf(beta1, t);
   const float bc2s = sqrtf(1.f - powf(beta2, t));
@@ -154,13 +155,47 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 }
 
 extern "C" int mi355_adamw(float* p, const float* g, float* m, float* v, long long n, const float* lr, float beta1,
-                           float beta2, float eps, float wd, const float* coef, float inv_scale, const float* found_inf,
-                           const int32_t* step, mi355_stream_t s) {
+                           float beta2, float eps, float wd, const float* coef, float inv_scale, const float* dev_scale,
+                           const float* found_inf, const int32_t* step, mi355_stream_t s) {
   MI355_CHECK_ARG(p && g && m && v && lr && step && n > 0, "adamw: bad arguments");
   long long blocks = (n + 255) / 256;
   if (blocks > 256 * 8) blocks = 256 * 8;
   hipLaunchKernelGGL(adamw_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)s, p, g, m, v, n, lr, beta1, beta2, eps, wd, coef,
-                     inv_scale, found_inf, step);
+                     inv_scale, dev_scale, found_inf, step);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+// ---- loss scaling (torch.amp.GradScaler semantics, all state on the device) -------------------------------------
+__global__ void step_tick_kernel(int32_t* step, const float* found_inf) {
+  if (!found_inf || found_inf[0] == 0.f) step[0] += 1;
+}
+
+extern "C" int mi355_step_tick(int32_t* step, const float* found_inf, mi355_stream_t s) {
+  MI355_CHECK_ARG(step, "step_tick: null pointer");
+  hipLaunchKernelGGL(step_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, step, found_inf);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+__global__ void amp_update_kernel(float* scale, float* inv_scale, int32_t* growth_tracker, const float* found_inf, float growth,
+                                  float backoff, int interval) {
+  if (found_inf[0] != 0.f) {
+    scale[0] *= backoff;
+    growth_tracker[0] = 0;
+  } else if (++growth_tracker[0] == interval) {
+    const float grown = scale[0] * growth;
+    if (isfinite(grown)) scale[0] = grown;     // (torch: never grow into infinity)
+    growth_tracker[0] = 0;
+  }
+  inv_scale[0] = 1.f / scale[0];
+}
+
+extern "C" int mi355_amp_update(float* scale, float* inv_scale, int32_t* growth_tracker, const float* found_inf, float growth,
+                                float backoff, int interval, mi355_stream_t s) {
+  MI355_CHECK_ARG(scale && inv_scale && growth_tracker && found_inf && interval > 0, "amp_update: bad arguments");
+  hipLaunchKernelGGL(amp_update_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, scale, inv_scale, growth_tracker, found_inf, growth,
+                     backoff, interval);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }

@@ -31,8 +31,9 @@ struct Wgrad3Args {
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
 
+template <typename T>
 __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args a) {
-  typedef bf16_t T;
+  static_assert(sizeof(T) == 2, "bf16 / fp16 only");
   constexpr int XPX = 40, XROW = XPX * 128, DROW = 32 * 128;      // row images in bytes
   constexpr int NRX = 4, NRD = 5;                 // live rows: X r..r+3, dY r-1..r+3 (NRX must be a power of two)
   constexpr int X_BYTES = NRX * XROW, D_BYTES = NRD * DROW;
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args 
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw)
-          acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kh], bf[kw], acc[kh * 3 + kw], 0, 0, 0);
+          acc[kh * 3 + kw] = mfma_32x32x16<T>(af[kh], bf[kw], acc[kh * 3 + kw]);
     };
     auto wrap = [](int v, int n) { return v >= n ? v - n : v; };
 

@@ -22,14 +22,14 @@ import torch.nn as nn
 from . import graph
 from .lib import lib
 
-_DEFAULT_DTYPE = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32,
-                  "float32": torch.float32}[os.environ.get("MI355_DTYPE", "bf16").lower()]
+_DEFAULT_DTYPE = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp16": torch.float16, "float16": torch.float16,
+                  "fp32": torch.float32, "float32": torch.float32}[os.environ.get("MI355_DTYPE", "bf16").lower()]
 
 
 def set_default_dtype(dtype):
-    """Compute/storage dtype of activations for models built afterwards (torch.bfloat16 or float32)."""
+    """Compute/storage dtype of activations for models built afterwards (torch.bfloat16, float16 or float32)."""
     global _DEFAULT_DTYPE
-    assert dtype in (torch.bfloat16, torch.float32)
+    assert dtype in (torch.bfloat16, torch.float16, torch.float32)
     _DEFAULT_DTYPE = dtype
 
 

@@ -227,7 +227,7 @@ class Builder:
         self.device = torch.device(device)
         self.dtype = dtype
         self.code = DTYPE_CODE[dtype]
-        self.esz = 2 if dtype == torch.bfloat16 else 4
+        self.esz = 4 if dtype == torch.float32 else 2
         self.epc = 16 // self.esz
         self.training = training
         self.want_grad = want_grad and training
@@ -455,7 +455,7 @@ class Builder:
     def igemm_tag(self, co, ci, k=1, s=1, Ho=0, Wo=0, dgrad=False, up=False):
         """Kernel variant mi355_conv2d_igemm dispatches to (mirrors the launcher in csrc/conv_igemm.hip)."""
         bn = 128 if co % 128 == 0 else (64 if co % 64 == 0 else 32)
-        if self.dtype != torch.bfloat16:
+        if self.dtype == torch.float32:
             return f"conv_igemm_kernel<f32,{bn},16>"
         if k == 3 and s == 1 and co % 64 == 0 and not (dgrad and up):
             if Wo % 32 == 0 and Ho % 8 == 0:
@@ -470,7 +470,7 @@ class Builder:
         return "conv_igemm_dma_kernel<32,64,3>" if k64 else "conv_igemm_kernel<bf16,32,32>"
 
     def wgrad_tag(self, co, ci, k=1, s=1, Ho=0, Wo=0):
-        t = "bf16" if self.dtype == torch.bfloat16 else "f32"
+        t = "f32" if self.dtype == torch.float32 else "bf16"       # (the fp16 build runs the same variants as bf16)
         if t == "bf16" and k == 3 and s == 1 and Wo % 32 == 0 and Ho % 8 == 0:
             return "wgrad3x3_halo_kernel"
         return f"conv_wgrad_kernel<{t},{128 if co % 128 == 0 else 64},{128 if ci % 128 == 0 else 64}>"

@@ -19,8 +19,8 @@ REPO_ROOT = os.path.dirname(os.path.dirname(_HERE))
 HEADER = os.path.join(REPO_ROOT, "include", "mi355conv.h")
 SO_PATH = os.environ.get("MI355_LIB") or os.path.join(_HERE, "libmi355conv.so")   # MI355_LIB: A/B another build
 
-F32, BF16 = 0, 1
-DTYPE_CODE = {torch.float32: F32, torch.bfloat16: BF16}
+F32, BF16, F16 = 0, 1, 2
+DTYPE_CODE = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
 _CTYPES = {
     "int": ctypes.c_int, "float": ctypes.c_float, "long long": ctypes.c_longlong,

@@ -44,6 +44,29 @@ def _grad_buffer_of(params):
 class _Shared:
     """Clip state handed from clip_grad_norm_ to the next optimizer.step() on the same flat range."""
     by_buffer = {}
+    amp = {}          # flat parameter buffer pointer -> device 1/scale of an active loss scaler (amp.GradScaler.unscale_)
+
+
+def _clip_state(base, lo, hi):
+    st = _Shared.by_buffer.get((base.data_ptr(), lo, hi))
+    if st is None:
+        dev = base.device
+        st = {"partial": torch.empty(1024, device=dev), "norm": torch.zeros(1, device=dev),
+              "coef": torch.ones(1, device=dev), "finf": torch.zeros(1, device=dev), "fresh": False}
+        _Shared.by_buffer[(base.data_ptr(), lo, hi)] = st
+    return st
+
+
+def _norm_pass(base, g, lo, hi, max_norm, inv_scale):
+    """sum of squares of g[lo:hi] -> norm, clip coefficient, found_inf (device scalars)."""
+    lo4 = lo - lo % 4
+    nb = lib.mi355_rowreduce_blocks(hi - lo4)
+    st = _clip_state(base, lo, hi)
+    lib.mi355_sumsq_partial(g[lo4:hi], st["partial"], hi - lo4)
+    lib.mi355_clip_coef(st["partial"], nb, float(max_norm), float(inv_scale), _Shared.amp.get(base.data_ptr()), st["norm"],
+                        st["coef"], st["finf"], None)
+    st["fresh"] = True
+    return st
 
 
 def clip_grad_norm_(parameters: Iterable[torch.Tensor], max_norm: float, inv_scale: float = 1.0):
@@ -56,18 +79,7 @@ def clip_grad_norm_(parameters: Iterable[torch.Tensor], max_norm: float, inv_sca
         raise RuntimeError("mi355.optim.clip_grad_norm_ needs the parameters of a mi355 Net (flat storage); "
                            "there is no torch fallback on this path")
     base, g, lo, hi = r
-    n = hi - lo
-    lo4 = lo - lo % 4
-    nb = lib.mi355_rowreduce_blocks(hi - lo4)
-    st = _Shared.by_buffer.get((base.data_ptr(), lo, hi))
-    if st is None:
-        dev = base.device
-        st = {"partial": torch.empty(1024, device=dev), "norm": torch.zeros(1, device=dev),
-              "coef": torch.ones(1, device=dev), "finf": torch.zeros(1, device=dev), "fresh": False}
-        _Shared.by_buffer[(base.data_ptr(), lo, hi)] = st
-    lib.mi355_sumsq_partial(g[lo4:hi], st["partial"], hi - lo4)
-    lib.mi355_clip_coef(st["partial"], nb, float(max_norm), float(inv_scale), st["norm"], st["coef"], st["finf"], None)
-    st["fresh"] = True
+    st = _norm_pass(base, g, lo, hi, max_norm, inv_scale)
     return st["norm"].view(())
 
 
@@ -103,15 +115,20 @@ class AdamW(torch.optim.Optimizer):
                 st["lr_host"] = gr["lr"]
             lo, hi = st["lo"], st["hi"]
             clip = _Shared.by_buffer.get((st["p"].data_ptr(), lo, hi))
-            coef = st["one"]
+            amp_inv = _Shared.amp.get(st["p"].data_ptr())           # a loss scaler has unscale_()d this optimizer
+            if amp_inv is not None and not (clip is not None and clip["fresh"]):
+                clip = _norm_pass(st["p"], st["g"], lo, hi, 0.0, self.inv_scale)    # found_inf without clipping
+            coef, finf = st["one"], None
             if clip is not None and clip["fresh"]:
                 coef = clip["coef"]
                 clip["fresh"] = False
-            # tick the device-side step counter (norm/coef outputs go to scratch)
-            lib.mi355_clip_coef(st["scratch"], 0, 0.0, 1.0, st["scratch"], st["scratch"][1:], None, st["step"])
+                if amp_inv is not None:
+                    finf = clip["finf"]                              # GradScaler.step: skip on inf / nan gradients
+            st["finf"] = finf
+            lib.mi355_step_tick(st["step"], finf)
             b1, b2 = gr["betas"]
             lib.mi355_adamw(st["p"][lo:hi], st["g"][lo:hi], st["m"], st["v"], hi - lo, st["lr"], float(b1), float(b2),
-                            float(gr["eps"]), float(gr["weight_decay"]), coef, float(self.inv_scale), None, st["step"])
+                            float(gr["eps"]), float(gr["weight_decay"]), coef, float(self.inv_scale), amp_inv, finf, st["step"])
         return None
 
     def zero_grad(self, set_to_none: bool = True):

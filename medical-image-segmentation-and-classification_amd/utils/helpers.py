@@ -2,8 +2,9 @@
 printed lines as the reference's utils/helpers.py (acc/iou :219-227, factories :124-213,
 train :231-412), executing on the HIP launch-plan engine.
 
-Differences that do not change results: bf16/fp32 compute instead of fp16-autocast + GradScaler
-(no loss scaling needed), the per-step ``loss.item()`` host syncs (helpers.py:337,341) are replaced
+Differences that do not change results: the compute dtype is a property of the model (bf16 default, fp32,
+or fp16 with the device-side ``mi355.amp.GradScaler`` in the place of ``torch.amp.GradScaler``,
+helpers.py:285,323-336) instead of autocast, the per-step ``loss.item()`` host syncs (helpers.py:337,341) are replaced
 by device-side accumulation read back once per epoch, and model factories construct the local
 classes directly (the reference first tries a torch.hub download, helpers.py:158-166, which has
 no network here)."""
@@ -14,6 +15,7 @@ import time
 import torch
 import torch.nn as nn
 
+from mi355 import amp as mamp
 from mi355 import nn as mnn
 from mi355 import optim as moptim
 from mi355.lib import lib
@@ -118,6 +120,9 @@ def train(model, train_dl, val_dl, device, epochs, lr, name, save_dir, seg=False
         optimizer = _make_optimizer(head_params, 1e-4)
         scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=STAGE1)
 
+    # helpers.py:285 — scaling is enabled exactly where the reference's autocast would compute in fp16
+    from mi355 import engine as _engine
+    scaler = mamp.GradScaler(enabled=(getattr(model, "compute_dtype", None) or _engine._DEFAULT_DTYPE) == torch.float16)
     best_score = float("inf") if seg else 0.0
     patience, stale = 10, 0
     t0 = time.time()
@@ -143,9 +148,11 @@ def train(model, train_dl, val_dl, device, epochs, lr, name, save_dir, seg=False
             if seg and out.dim() == 3:
                 out = out.unsqueeze(1)
             loss = criterion(out, y)
-            loss.backward()
+            scaler.scale(loss).backward()
+            scaler.unscale_(optimizer)
             moptim.clip_grad_norm_(model.parameters(), max_norm=1.0)
-            optimizer.step()
+            scaler.step(optimizer)
+            scaler.update()
             loss_sum += loss.detach() * x.size(0)
             if not seg:
                 hit_sum += (torch.argmax(out.detach(), 1) == y).sum()

@@ -1,6 +1,6 @@
 """-m gpu: implicit-GEMM conv (forward, data gradient, ConvTranspose) through the C ABI vs
-torch CPU fp32 (F.conv2d / autograd).  Tolerances: fp32 1e-4 relative-to-max; bf16 compares
-against the CPU result on bf16-rounded operands, 2e-2 relative-to-max (output rounding 2^-8)."""
+torch CPU fp32 (F.conv2d / autograd).  Tolerances: fp32 1e-4 relative-to-max; bf16 / fp16 compare
+against the CPU result on operands rounded to that type: 2e-2 / 3e-3 relative-to-max (output rounding 2^-8 / 2^-11)."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -8,7 +8,8 @@ import torch.nn.functional as F
 from gpu_util import DEV, lib, to_nhwc, from_nhwc, pack_w, rel_err, q, DTYPE_CODE
 
 pytestmark = pytest.mark.gpu
-TOL = {torch.float32: 1e-4, torch.bfloat16: 2e-2}
+TOL = {torch.float32: 1e-4, torch.bfloat16: 2e-2, torch.float16: 3e-3}
+DT = [torch.float32, torch.bfloat16, torch.float16]
 
 CASES = [  # N, Ci, H, W, Co, K, stride, pad, up
     (2, 32, 12, 12, 64, 3, 1, 1, 0),
@@ -35,7 +36,7 @@ def _conv_ref(x, w, b, s, p, up):
     return F.conv2d(x, w, b, stride=s, padding=p)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("case", CASES)
 def test_conv_fwd(case, dtype):
     n, ci, h, w_, co, k, s, p, up = case
@@ -54,7 +55,7 @@ def test_conv_fwd(case, dtype):
     assert rel_err(from_nhwc(y), ref) < TOL[dtype]
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("case", [c for c in CASES if not c[8]])
 def test_conv_dgrad(case, dtype):
     n, ci, h, w_, co, k, s, p, up = case
@@ -76,7 +77,7 @@ def test_conv_dgrad(case, dtype):
     assert rel_err(from_nhwc(dx), ref) < TOL[dtype]
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DT)
 def test_conv_strided_slices_and_accumulate(dtype):
     """input read from / output written into channel slices of wider buffers; accumulate flag."""
     n, ci, h, w_, co = 2, 32, 8, 8, 64
@@ -97,7 +98,7 @@ def test_conv_strided_slices_and_accumulate(dtype):
     assert torch.equal(got[..., :32], base.float()[..., :32]) and torch.equal(got[..., 96:], base.float()[..., 96:])
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DT)
 def test_conv_transpose_2x2(dtype):
     n, ci, h, w_, co = 2, 64, 5, 6, 32
     g = torch.Generator().manual_seed(11)
@@ -139,7 +140,7 @@ WG_CASES = [  # N, Ci, H, W, Co, K, stride, pad, up
 ]
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("case", WG_CASES)
 def test_conv_wgrad(case, dtype):
     n, ci, h, w_, co, k, s, p, up = case
@@ -170,9 +171,9 @@ def test_conv_wgrad(case, dtype):
 
 @pytest.mark.parametrize("case", [(2, 64, 16, 32, 128, 3, 1, 1, 0), (2, 96, 16, 16, 64, 3, 1, 1, 0), (3, 64, 9, 7, 64, 1, 1, 0, 0),
                                   (2, 64, 8, 16, 128, 3, 1, 1, 1), (1, 32, 5, 5, 128, 3, 2, 1, 0)])
-def test_conv_fused_bn_statistics(case):
-    """bf16 kernels fold the BatchNorm partial sums of the (rounded) outputs into their epilogue."""
-    dtype = torch.bfloat16
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_conv_fused_bn_statistics(case, dtype):
+    """bf16 / fp16 kernels fold the BatchNorm partial sums of the (rounded) outputs into their epilogue."""
     n, ci, h, w_, co, k, s, p, up = case
     g = torch.Generator().manual_seed(99)
     x = torch.randn(n, ci, h, w_, generator=g); w = torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5

@@ -10,8 +10,8 @@ import torch.nn.functional as F
 from gpu_util import DEV, lib, to_nhwc, from_nhwc, pack_w, rel_err, q, DTYPE_CODE
 
 pytestmark = pytest.mark.gpu
-DT = [torch.float32, torch.bfloat16]
-TOL = {torch.float32: 2e-5, torch.bfloat16: 1.2e-2}
+DT = [torch.float32, torch.bfloat16, torch.float16]
+TOL = {torch.float32: 2e-5, torch.bfloat16: 1.2e-2, torch.float16: 2e-3}
 
 
 def dev(t):
@@ -27,7 +27,7 @@ def _partials(m, c, nq=2):
 @pytest.mark.parametrize("shape", [(2, 32, 9, 7), (3, 64, 16, 16), (2, 96, 5, 5), (1, 1024, 4, 4), (4, 8, 40, 40)])
 def test_bn_forward_train(shape, dtype):
     n, c, h, w = shape
-    if dtype == torch.float32 and c % 4 or dtype == torch.bfloat16 and c % 8:
+    if dtype == torch.float32 and c % 4 or dtype != torch.float32 and c % 8:
         pytest.skip("chunk multiple")
     g = torch.Generator().manual_seed(c)
     x = q(torch.randn(shape, generator=g) * 2 + 0.5, dtype)
@@ -312,8 +312,8 @@ def test_clip_and_adamw_match_torch():
         opt.step()
         gd = dev(gr)
         lib.mi355_sumsq_partial(gd, part, n)
-        lib.mi355_clip_coef(part, nb, 1.0, 1.0, norm, coef, finf, step)
-        lib.mi355_adamw(pd, gd, m, v, n, lr, 0.9, 0.999, 1e-8, 5e-4, coef, 1.0, finf, step)
+        lib.mi355_clip_coef(part, nb, 1.0, 1.0, None, norm, coef, finf, step)
+        lib.mi355_adamw(pd, gd, m, v, n, lr, 0.9, 0.999, 1e-8, 5e-4, coef, 1.0, None, finf, step)
         torch.cuda.synchronize()
         assert abs(float(norm) - float(tn)) < 1e-4 * float(tn)
         assert rel_err(pd.cpu(), p.detach()) < 1e-6
@@ -322,10 +322,30 @@ def test_clip_and_adamw_match_torch():
     gd = dev(torch.full((n,), float("inf")))
     before = pd.clone()
     lib.mi355_sumsq_partial(gd, part, n)
-    lib.mi355_clip_coef(part, nb, 1.0, 1.0, norm, coef, finf, step)
-    lib.mi355_adamw(pd, gd, m, v, n, lr, 0.9, 0.999, 1e-8, 5e-4, coef, 1.0, finf, step)
+    lib.mi355_clip_coef(part, nb, 1.0, 1.0, None, norm, coef, finf, step)
+    lib.mi355_adamw(pd, gd, m, v, n, lr, 0.9, 0.999, 1e-8, 5e-4, coef, 1.0, None, finf, step)
     torch.cuda.synchronize()
     assert torch.equal(pd, before) and int(step) == 3 and float(finf) == 1.0
+    # device-side loss scale: gradients carry a factor 1024, dev_scale = 1/1024 restores the step and the norm
+    gr = torch.randn(n, generator=g)
+    p.grad = gr.clone()
+    tn = torch.nn.utils.clip_grad_norm_([p], 1.0)
+    opt.step()
+    gd = dev(gr * 1024.0); inv = torch.tensor([1.0 / 1024.0], device=DEV)
+    lib.mi355_sumsq_partial(gd, part, n)
+    lib.mi355_clip_coef(part, nb, 1.0, 1.0, inv, norm, coef, finf, None)
+    lib.mi355_step_tick(step, finf)
+    lib.mi355_adamw(pd, gd, m, v, n, lr, 0.9, 0.999, 1e-8, 5e-4, coef, 1.0, inv, finf, step)
+    torch.cuda.synchronize()
+    assert int(step) == 4 and abs(float(norm) - float(tn)) < 1e-4 * float(tn) and rel_err(pd.cpu(), p.detach()) < 1e-6
+    # scale update rule (torch.amp.GradScaler.update)
+    scale = torch.tensor([65536.0], device=DEV); iv = torch.tensor([1 / 65536.0], device=DEV)
+    tr = torch.zeros(1, dtype=torch.int32, device=DEV); one = torch.ones(1, device=DEV); zero = torch.zeros(1, device=DEV)
+    lib.mi355_amp_update(scale, iv, tr, one, 2.0, 0.5, 3)
+    assert float(scale) == 32768.0 and int(tr) == 0 and float(iv) == 1 / 32768.0
+    for k in range(3):
+        lib.mi355_amp_update(scale, iv, tr, zero, 2.0, 0.5, 3)
+        assert float(scale) == (65536.0 if k == 2 else 32768.0) and int(tr) == (0 if k == 2 else k + 1)
 
 
 def test_seg_counts():

@@ -1,8 +1,9 @@
 """-m gpu: the north-star Dice criterion.  Train Attention U-Net for 40 optimiser steps on a learnable
 synthetic task (ellipse visible in the image) three ways from identical weights and batches —
-HIP bf16, HIP fp32, CPU fp32 oracle (reference semantics: BCEWithLogits, clip 1.0, AdamW wd 5e-4) —
+HIP bf16, HIP fp16 (+ loss scaling, helpers.py:285,323-336), HIP fp32, CPU fp32 oracle (reference semantics:
+BCEWithLogits, clip 1.0, AdamW wd 5e-4) —
 and compare the Dice of the binarised predictions (tester.py:114-134) on 32 held-out images.
-Bound: |Dice - Dice_oracle| <= 1e-3 (0..1 scale) for both GPU modes; final losses within 2 %."""
+Bound: |Dice - Dice_oracle| <= 1e-3 (0..1 scale) for every GPU mode; final losses within 2 %."""
 import pytest
 import torch
 
@@ -25,7 +26,7 @@ def _dice(logit, m):
 
 
 def test_dice_after_training_matches_oracle():
-    from mi355 import nn as mnn, optim as moptim
+    from mi355 import nn as mnn, optim as moptim, amp as mamp
     from models.segmentation_models.AttentionUNet import AttentionUNet
     hw, b, steps, lr = 64, 4, 40, 1e-3
     batches = [_task(b, hw, s) for s in range(4)]
@@ -41,20 +42,33 @@ def test_dice_after_training_matches_oracle():
         ref_dice = _dice(nets.attention_unet({k: v.clone() for k, v in sd.items()}, xv, True), mv)
     assert ref_dice > 0.95          # the task is learnable: the comparison is not degenerate
 
-    for dtype in (torch.float32, torch.bfloat16):
+    for dtype in (torch.float32, torch.bfloat16, torch.float16):
         m = AttentionUNet()
         m.load_state_dict(sd0)
         m.compute_dtype = dtype
         m = m.to(DEV).train()
         o = moptim.AdamW(m.parameters(), lr=lr, weight_decay=5e-4)
         crit = mnn.BCEWithLogitsLoss()
-        for i in range(steps):
-            x, y = batches[i % 4]
+        # the reference's sequence (helpers.py:320-336); the scaler is a no-op unless fp16.  A small growth interval
+        # makes the scale move inside the 40 steps, and the first steps overflow (d loss / d logit = 2^34 / 16384 > 65504)
+        scaler = mamp.GradScaler(init_scale=2.0 ** 34, growth_interval=8, enabled=dtype == torch.float16)
+        done = it = 0
+        while done < steps and it < steps + 24:
+            x, y = batches[done % 4]                     # a skipped (overflowed) step is repeated on the same batch
             o.zero_grad(set_to_none=True)
             loss = crit(m(x.to(DEV)), y.to(DEV))
-            loss.backward()
+            scaler.scale(loss).backward()
+            scaler.unscale_(o)
             moptim.clip_grad_norm_(m.parameters(), 1.0)
-            o.step()
+            scaler.step(o)
+            scaler.update()
+            it += 1
+            done = int(o._st[0]["step"])
+        assert done == steps
+        if dtype == torch.float16:
+            assert it > steps and scaler.get_scale() < 2.0 ** 34       # overflow steps were skipped, the scale backed off
+        else:
+            assert it == steps
         with torch.no_grad():
             d = _dice(m(xv.to(DEV)).float().cpu(), mv)       # train-mode BN, like the oracle evaluation above
         assert abs(d - ref_dice) <= 1e-3, (str(dtype), d, ref_dice)

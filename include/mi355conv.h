@@ -229,6 +229,17 @@ int mi355_amp_update(float* scale, float* inv_scale, int32_t* growth_tracker, co
                      float backoff, int interval, mi355_stream_t s);
 int mi355_fill_f32(float* p, float v, long long n, mi355_stream_t s);
 
+/* ---- joint inference pipeline glue (utils/pipeline.py:324-357 classify, 359-418 process_image) ---------- */
+/* pred[b] = argmax_c logits[b][c] (first maximum), conf[b] = 100 * max softmax; kept[0..n_kept) = the batch indices
+ * with pred == keep_class, in order.  B <= 1024. */
+int mi355_cls_decide(const float* logits, int B, int C, int keep_class, int32_t* pred, float* conf, int32_t* kept,
+                     int32_t* n_kept, mi355_stream_t s);
+/* y[i] = x[idx[i]], rows of `row` fp32 elements (row % 4 == 0): compacts the kept images. */
+int mi355_gather_rows(const float* x, const int32_t* idx, int n, long long row, float* y, mi355_stream_t s);
+/* out[idx[i]][p] = sigmoid(logit[i][p]) > thr ? 255 : 0 (pipeline.py:350-352); out is [B][per] uint8, zeroed by the caller. */
+int mi355_mask_scatter(const float* logit, const int32_t* idx, int n, long long per, float thr, uint8_t* out,
+                       mi355_stream_t s);
+
 /* ---- segmentation metrics counters (utils/tester.py:92-193; helpers.py:223-227) ------------- */
 /* per sample b: counts[b*4+{0,1,2,3}] = tp, pred-positive, target-positive, equal   (p = prob > thr) */
 int mi355_seg_counts(const float* prob_or_logit, const float* target, float* counts, int B, long long per,

@@ -189,3 +189,78 @@ extern "C" int mi355_dropout_bwd(const float* dy, const uint8_t* mask, float* dx
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }
+
+// ---- joint pipeline glue (utils/pipeline.py:324-357, 359-418) --------------------------------------------------------
+// classify -> keep the samples of one class -> segment those -> binary masks.  Per sample: pred = argmax softmax,
+// conf = 100 * max softmax; the kept samples' batch indices are compacted in order (the count goes back to the
+// host once, to size the segmentation launch).
+__global__ void cls_decide_kernel(const float* __restrict__ logits, int B, int C, int keep_class, int32_t* __restrict__ pred,
+                                  float* __restrict__ conf, int32_t* __restrict__ kept, int32_t* __restrict__ n_kept) {
+  __shared__ int flag[1024];
+  const int b = threadIdx.x;
+  int mine = 0;
+  if (b < B) {
+    const float* z = logits + (size_t)b * C;
+    float m = z[0];
+    int am = 0;
+    for (int c = 1; c < C; ++c)
+      if (z[c] > m) { m = z[c]; am = c; }          // first maximum (torch.max tie rule)
+    float den = 0.f;
+    for (int c = 0; c < C; ++c) den += expf(z[c] - m);
+    pred[b] = am;
+    conf[b] = 100.f / den;
+    mine = am == keep_class;
+  }
+  flag[b] = mine;
+  __syncthreads();
+  if (b == 0) {
+    int n = 0;
+    for (int i = 0; i < B; ++i)
+      if (flag[i]) kept[n++] = i;
+    n_kept[0] = n;
+  }
+}
+
+extern "C" int mi355_cls_decide(const float* logits, int B, int C, int keep_class, int32_t* pred, float* conf, int32_t* kept,
+                                int32_t* n_kept, mi355_stream_t s) {
+  MI355_CHECK_ARG(logits && pred && conf && kept && n_kept && B > 0 && B <= 1024 && C > 0, "cls_decide: bad arguments (B=%d)", B);
+  hipLaunchKernelGGL(cls_decide_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, logits, B, C, keep_class, pred, conf, kept, n_kept);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+// y[i] = x[idx[i]] for rows of `row` fp32 elements (row % 4 == 0): the kept images, compacted
+__global__ void gather_rows_kernel(const float4* __restrict__ x, const int32_t* __restrict__ idx, long long row4,
+                                   float4* __restrict__ y) {
+  const float4* src = x + (size_t)idx[blockIdx.y] * row4;
+  float4* dst = y + (size_t)blockIdx.y * row4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < row4; i += (long long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+extern "C" int mi355_gather_rows(const float* x, const int32_t* idx, int n, long long row, float* y, mi355_stream_t s) {
+  MI355_CHECK_ARG(x && idx && y && n > 0 && row > 0 && row % 4 == 0, "gather_rows: bad arguments");
+  long long bx = (row / 4 + 255) / 256;
+  if (bx > 256) bx = 256;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((int)bx, n), dim3(256), 0, (hipStream_t)s, (const float4*)x, idx, row / 4, (float4*)y);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
+// out[idx[i]][p] = sigmoid(logit[i][p]) > thr ? 255 : 0 for the n compacted samples (out: [B][per] uint8, zeroed by the caller)
+__global__ void mask_scatter_kernel(const float* __restrict__ logit, const int32_t* __restrict__ idx, long long per, float thr,
+                                    uint8_t* __restrict__ out) {
+  const float* src = logit + (size_t)blockIdx.y * per;
+  uint8_t* dst = out + (size_t)idx[blockIdx.y] * per;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long long)gridDim.x * blockDim.x)
+    dst[i] = 1.f / (1.f + expf(-src[i])) > thr ? 255 : 0;
+}
+
+extern "C" int mi355_mask_scatter(const float* logit, const int32_t* idx, int n, long long per, float thr, uint8_t* out,
+                                  mi355_stream_t s) {
+  MI355_CHECK_ARG(logit && idx && out && n > 0 && per > 0, "mask_scatter: bad arguments");
+  long long bx = (per + 255) / 256;
+  if (bx > 256) bx = 256;
+  hipLaunchKernelGGL(mask_scatter_kernel, dim3((int)bx, n), dim3(256), 0, (hipStream_t)s, logit, idx, per, thr, out);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}

@@ -229,7 +229,8 @@ def main():
         ms = elapsed / args.steps * 1e3
         value = args.batch * world * args.steps / elapsed
         result = {
-            "metric": "images/sec (train step) Attention U-Net 256x256 bs=32/GPU",
+            "metric": f"images/sec (train step) {'Attention U-Net' if args.model == 'AttentionUNet' else args.model} "
+                      f"{args.size}x{args.size} bs={args.batch}/GPU",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",

@@ -1,0 +1,106 @@
+"""-m gpu: the data-parallel step end to end with REAL kernels and streams, world_size 2.
+Both ranks share the one GPU of the test box (RCCL needs one device per rank, so the exchange runs over gloo on
+CUDA tensors — the bucket schedule, the comm / side-stream event edges, the inv_scale folding and the kernels are
+the production ones).  Checks after two optimiser steps of Attention U-Net (bf16, several gradient buckets):
+  * both ranks hold bit-identical parameters;
+  * they equal a single-process emulation: gradients of shard 0 and shard 1 computed one after the other from the
+    same weights, summed, then clip(1.0) + AdamW with inv_scale = 1/2 (train-mode BN statistics stay per shard, as
+    in DDP without SyncBN — SURVEY.md §8e)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+STEPS, B, HW, LR = 2, 4, 64, 1e-3
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _setup():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "medical-image-segmentation-and-classification_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from oracle import nets, train as otrain
+    from models.segmentation_models.AttentionUNet import AttentionUNet
+    m = AttentionUNet()
+    m.load_state_dict(nets.default_init_state("AttentionUNet", seed=0))
+    m.compute_dtype = torch.bfloat16
+    m = m.to(DEV).train()
+    shards = [[otrain.synthetic_batch(B, HW, seed=10 * s + r) for s in range(STEPS)] for r in range(2)]
+    return m, shards
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m, shards = _setup()
+        from mi355 import nn as mnn, optim as moptim
+        from mi355.dp import DataParallel
+        dp = DataParallel(m, bucket_mb=8.0, overlap=True)
+        assert dp.world == 2
+        opt = moptim.AdamW(m.parameters(), lr=LR, weight_decay=5e-4)
+        opt.inv_scale = dp.inv_scale
+        crit = mnn.BCEWithLogitsLoss()
+        for s in range(STEPS):
+            x, y = shards[rank][s]
+            opt.zero_grad(set_to_none=True)
+            loss = crit(dp(x.to(DEV)), y.to(DEV))
+            loss.backward()
+            moptim.clip_grad_norm_(m.parameters(), 1.0, inv_scale=dp.inv_scale)
+            opt.step()
+        torch.cuda.synchronize()
+        plan = [p for p in m.engine.plans.values() if p.dout is not None][0]
+        q.put((rank, "ok", m.engine.flat_p.detach().cpu(), len(dp.schedule(plan))))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "fail", traceback.format_exc(), 0))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_world2_matches_single_process_emulation():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=400) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status, info, _ in res:
+        assert status == "ok", f"rank {rank}: {info}"
+    p0, p1 = res[0][2], res[1][2]
+    assert res[0][3] > 1                              # 140 MB of gradients in 8 MB buckets: the overlap path ran
+    assert torch.equal(p0, p1)                        # same reduced gradients + same update => bit-identical replicas
+
+    m, shards = _setup()
+    from mi355 import nn as mnn, optim as moptim
+    opt = moptim.AdamW(m.parameters(), lr=LR, weight_decay=5e-4)
+    opt.inv_scale = 0.5
+    crit = mnn.BCEWithLogitsLoss()
+    eng = m.engine
+    for s in range(STEPS):
+        total = None
+        for r in range(2):
+            x, y = shards[r][s]
+            opt.zero_grad(set_to_none=True)
+            crit(m(x.to(DEV)), y.to(DEV)).backward()
+            total = eng.flat_g.clone() if total is None else total + eng.flat_g
+        eng.flat_g.copy_(total)
+        moptim.clip_grad_norm_(m.parameters(), 1.0, inv_scale=0.5)
+        opt.step()
+    torch.cuda.synchronize()
+    ref = eng.flat_p.detach().cpu()
+    err = float((p0 - ref).abs().max() / ref.abs().max())
+    assert err <= 1e-6, err

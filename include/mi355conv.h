@@ -229,6 +229,13 @@ int mi355_amp_update(float* scale, float* inv_scale, int32_t* growth_tracker, co
                      float backoff, int interval, mi355_stream_t s);
 int mi355_fill_f32(float* p, float v, long long n, mi355_stream_t s);
 
+/* AdaptiveAvgPool2d((OH,OW)) + Flatten of the torchvision VGG head (helpers.py:158-166 loads `vgg16_bn`):
+ * NHWC `dtype` activations -> fp32 [N][C*OH*OW] in NCHW flatten order; backward writes (does not accumulate) dx. */
+int mi355_adaptive_avgpool_fwd(const void* x, int ldx, float* y, int N, int H, int W, int C, int OH, int OW, int dtype,
+                               mi355_stream_t s);
+int mi355_adaptive_avgpool_bwd(const float* dy, void* dx, int lddx, int N, int H, int W, int C, int OH, int OW, int dtype,
+                               mi355_stream_t s);
+
 /* ---- joint inference pipeline glue (utils/pipeline.py:324-357 classify, 359-418 process_image) ---------- */
 /* pred[b] = argmax_c logits[b][c] (first maximum), conf[b] = 100 * max softmax; kept[0..n_kept) = the batch indices
  * with pred == keep_class, in order.  B <= 1024. */

@@ -264,3 +264,76 @@ extern "C" int mi355_mask_scatter(const float* logit, const int32_t* idx, int n,
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }
+
+// ---- AdaptiveAvgPool2d((OH,OW)) + Flatten (torchvision VGG: 512 x 7 x 7 -> 25088) --------------------------------
+// NHWC activations -> fp32 [N][C*OH*OW] in torch's NCHW flatten order; window of cell o: [floor(o*H/OH), ceil((o+1)*H/OH)).
+template <typename T>
+__global__ void adaptive_avgpool_fwd_kernel(const T* __restrict__ x, int ldx, float* __restrict__ y, int H, int W, int C, int OH,
+                                            int OW, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);                       // channel fastest: coalesced reads
+    long long r = i / C;
+    const int ow = (int)(r % OW); r /= OW;
+    const int oh = (int)(r % OH);
+    const int n = (int)(r / OH);
+    const int h0 = (oh * H) / OH, h1 = ((oh + 1) * H + OH - 1) / OH;
+    const int w0 = (ow * W) / OW, w1 = ((ow + 1) * W + OW - 1) / OW;
+    float acc = 0.f;
+    for (int h = h0; h < h1; ++h)
+      for (int w = w0; w < w1; ++w) acc += to_f32<T>(x[((size_t)(n * H + h) * W + w) * ldx + c]);
+    y[((size_t)n * C + c) * OH * OW + oh * OW + ow] = acc / (float)((h1 - h0) * (w1 - w0));
+  }
+}
+
+template <typename T>
+__global__ void adaptive_avgpool_bwd_kernel(const float* __restrict__ dy, T* __restrict__ dx, int lddx, int H, int W, int C, int OH,
+                                            int OW, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long long r = i / C;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H);
+    const int n = (int)(r / H);
+    float acc = 0.f;
+    for (int oh = 0; oh < OH; ++oh) {
+      const int h0 = (oh * H) / OH, h1 = ((oh + 1) * H + OH - 1) / OH;
+      if (h < h0 || h >= h1) continue;
+      for (int ow = 0; ow < OW; ++ow) {
+        const int w0 = (ow * W) / OW, w1 = ((ow + 1) * W + OW - 1) / OW;
+        if (w < w0 || w >= w1) continue;
+        acc += dy[((size_t)n * C + c) * OH * OW + oh * OW + ow] / (float)((h1 - h0) * (w1 - w0));
+      }
+    }
+    dx[((size_t)(n * H + h) * W + w) * lddx + c] = from_f32<T>(acc);
+  }
+}
+
+extern "C" int mi355_adaptive_avgpool_fwd(const void* x, int ldx, float* y, int N, int H, int W, int C, int OH, int OW, int dtype,
+                                          mi355_stream_t s) {
+  MI355_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0, "adaptive_avgpool_fwd: bad arguments");
+  const long long total = (long long)N * OH * OW * C;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  return dispatch_dtype(dtype, "adaptive_avgpool_fwd", [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((adaptive_avgpool_fwd_kernel<T>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx, y, H, W, C,
+                       OH, OW, total);
+    MI355_LAUNCH_CHECK();
+    return (int)MI355_OK;
+  });
+}
+
+extern "C" int mi355_adaptive_avgpool_bwd(const float* dy, void* dx, int lddx, int N, int H, int W, int C, int OH, int OW, int dtype,
+                                          mi355_stream_t s) {
+  MI355_CHECK_ARG(dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0, "adaptive_avgpool_bwd: bad arguments");
+  const long long total = (long long)N * H * W * C;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  return dispatch_dtype(dtype, "adaptive_avgpool_bwd", [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((adaptive_avgpool_bwd_kernel<T>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, dy, (T*)dx, lddx, H, W, C, OH,
+                       OW, total);
+    MI355_LAUNCH_CHECK();
+    return (int)MI355_OK;
+  });
+}

@@ -839,6 +839,23 @@ class Builder:
         self.rule(rule)
         return v
 
+    def adaptive_avgpool(self, x, oh, ow):
+        """nn.AdaptiveAvgPool2d((oh, ow)) + Flatten -> fp32 [N, C*oh*ow] in NCHW order (torchvision VGG head)."""
+        v = V(self.f32(x.N * x.C * oh * ow), x.N, x.C * oh * ow)
+        self.fwd.append(Launch("mi355_adaptive_avgpool_fwd", x, x.ld, v, x.N, x.H, x.W, x.C, oh, ow, self.code))
+        v.needs_grad = x.needs_grad
+
+        def rule():
+            if not v.needs_grad:
+                return
+            dv = self.grad_of(v)
+            if self.acc_flag(x):
+                raise NotImplementedError("adaptive_avgpool input with several consumers")
+            xg = self.grad_of(x)
+            self.bwd.append(Launch("mi355_adaptive_avgpool_bwd", dv, xg, xg.ld, x.N, x.H, x.W, x.C, oh, ow, self.code))
+        self.rule(rule)
+        return v
+
     def linear(self, v, lin, relu=False, is_output=False):
         O = lin.out_features
         y = V(self.f32(v.B * O), v.B, O)
@@ -934,7 +951,12 @@ class Builder:
                 x = self.seq(m, x, out=out if last(i) else None)
                 i += 1
             elif isinstance(m, (nn.AdaptiveAvgPool2d, nn.AdaptiveMaxPool2d)):
-                x = self.global_pool(x, isinstance(m, nn.AdaptiveMaxPool2d))
+                osz = m.output_size if isinstance(m.output_size, (tuple, list)) else (m.output_size, m.output_size)
+                if tuple(osz) == (1, 1):
+                    x = self.global_pool(x, isinstance(m, nn.AdaptiveMaxPool2d))
+                else:
+                    assert isinstance(m, nn.AdaptiveAvgPool2d), "AdaptiveMaxPool2d: only output size 1"
+                    x = self.adaptive_avgpool(x, int(osz[0]), int(osz[1]))
                 i += 1
             elif isinstance(m, nn.Flatten) or isinstance(m, nn.Identity):
                 i += 1

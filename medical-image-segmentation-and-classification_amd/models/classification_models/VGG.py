@@ -1,5 +1,11 @@
 """VGG16 / VGG19 without BatchNorm + 3-layer MLP head (reference VGG.py:3-152) on the MI355X
-engine; ``features.N`` / ``classifier.N`` indices match the reference Sequentials."""
+engine; ``features.N`` / ``classifier.N`` indices match the reference Sequentials.
+
+``VGG16_BN`` / ``VGG19_BN`` are the torchvision ``vgg16_bn`` / ``vgg19_bn`` layouts the reference asks
+``torch.hub`` for first (helpers.py:158-166, pipeline.py:82-89: ``name + "_bn"``): [Conv3x3 -> BatchNorm ->
+ReLU] stacks, ``avgpool = AdaptiveAvgPool2d((7, 7))``, ``classifier = Linear(25088, 4096) -> ReLU ->
+Dropout -> Linear(4096, 4096) -> ReLU -> Dropout -> Linear(4096, num_classes)`` — same ``state_dict``
+keys and shapes, so torchvision checkpoints load."""
 import torch.nn as nn
 
 from mi355.engine import Net
@@ -58,3 +64,39 @@ class VGG16(_VGG):
 
 class VGG19(_VGG):
     FEATURES = VGG19_Features
+
+
+def _features_bn(cfg):
+    layers, cin = [], 3
+    for c in cfg:
+        if c == "M":
+            layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+        else:
+            layers += [nn.Conv2d(cin, c, kernel_size=3, padding=1), nn.BatchNorm2d(c), nn.ReLU(inplace=True)]
+            cin = c
+    return nn.Sequential(*layers)
+
+
+class _VGG_BN(Net):
+    CFG = None
+
+    def __init__(self, num_classes=1000, dropout=0.5):
+        super().__init__()
+        self.features = _features_bn(self.CFG)
+        self.avgpool = nn.AdaptiveAvgPool2d((7, 7))
+        self.classifier = nn.Sequential(nn.Linear(512 * 7 * 7, 4096), nn.ReLU(True), nn.Dropout(p=dropout),
+                                        nn.Linear(4096, 4096), nn.ReLU(True), nn.Dropout(p=dropout),
+                                        nn.Linear(4096, num_classes))
+
+    def build(self, g, x):
+        t = g.seq(self.features, x)
+        v = g.seq([self.avgpool], t)
+        g.head(self.classifier, v)
+
+
+class VGG16_BN(_VGG_BN):
+    CFG = _CFG16
+
+
+class VGG19_BN(_VGG_BN):
+    CFG = _CFG19

@@ -41,9 +41,13 @@ def add_dropout_to_fc(model, p=0.5, classes=CLASSES):
 
 
 def get_class_model(name):
-    """name -> (model, head attribute name); local architectures, random init (helpers.py:170-192)."""
+    """name -> (model, head attribute name); random init.  The reference first asks torch.hub for the torchvision
+    model (`vgg16` -> `vgg16_bn`, helpers.py:158-166) and falls back to its local classes when that fails
+    (:170-192); there is no network here, so "vgg16" / "vgg19" / "resnet*" are the local classes (the reference's
+    offline behaviour) and the hub layouts are reachable by their own names "vgg16_bn" / "vgg19_bn"."""
     from models.classification_models import ResNet, VGG
-    table = {"resnet18": ResNet.ResNet18, "resnet50": ResNet.ResNet50, "vgg16": VGG.VGG16, "vgg19": VGG.VGG19}
+    table = {"resnet18": ResNet.ResNet18, "resnet50": ResNet.ResNet50, "vgg16": VGG.VGG16, "vgg19": VGG.VGG19,
+             "vgg16_bn": VGG.VGG16_BN, "vgg19_bn": VGG.VGG19_BN}
     key = name.lower()
     if key not in table:
         raise ValueError(f"Unknown classification model: {name}")

@@ -230,6 +230,43 @@ def _vgg(sd, x, cfg, training, drop_masks):
     return _linear(sd, "classifier.8", x)
 
 
+def _vgg_bn(sd, x, cfg, training, drop_masks):
+    """torchvision vgg16_bn / vgg19_bn (the models helpers.py:158-166 / pipeline.py:82-89 request from torch.hub),
+    restated from the public torchvision layout (torchvision is absent here: PARITY UNPINNED at this boundary):
+    features = [Conv3x3 p1 + bias -> BN -> ReLU]* with 2x2 max-pools, avgpool = AdaptiveAvgPool2d((7,7)), classifier =
+    Linear(25088,4096) ReLU Dropout Linear(4096,4096) ReLU Dropout Linear(4096,n); add_dropout_to_fc moves the last
+    Linear from classifier.6 to classifier.7 behind an extra Dropout (helpers.py:135-143)."""
+    idx = 0
+    for c in cfg:
+        if c == "M":
+            x = F.max_pool2d(x, 2, 2)
+            idx += 1
+        else:
+            x = F.relu(_bn(sd, f"features.{idx + 1}", _conv(sd, f"features.{idx}", x, 1, 1), training))
+            idx += 3
+    x = F.adaptive_avg_pool2d(x, (7, 7)).flatten(1)
+    dm = list(drop_masks) if (training and drop_masks is not None) else []
+    x = F.relu(_linear(sd, "classifier.0", x))
+    if dm:
+        x = x * dm[0]
+    x = F.relu(_linear(sd, "classifier.3", x))
+    if dm:
+        x = x * dm[1]
+    if "classifier.7.weight" in sd:          # after add_dropout_to_fc
+        if len(dm) > 2:
+            x = x * dm[2]
+        return _linear(sd, "classifier.7", x)
+    return _linear(sd, "classifier.6", x)
+
+
+def vgg16_bn(sd, x, training=False, drop_masks=None):
+    return _vgg_bn(sd, x, VGG16_CFG, training, drop_masks)
+
+
+def vgg19_bn(sd, x, training=False, drop_masks=None):
+    return _vgg_bn(sd, x, VGG19_CFG, training, drop_masks)
+
+
 def vgg16(sd, x, training=False, drop_masks=None):
     return _vgg(sd, x, VGG16_CFG, training, drop_masks)
 
@@ -287,6 +324,8 @@ NETS = {
     "VGG16": vgg16,
     "VGG19": vgg19,
     "ResNetUnet": resnet_unet,
+    "VGG16_BN": vgg16_bn,
+    "VGG19_BN": vgg19_bn,
 }
 
 
@@ -402,6 +441,17 @@ def spec(name, num_classes=3, head_dropout=False):
         s.linear("classifier.2", 512, 256)
         s.linear("classifier.5", 256, 256)
         s.linear("classifier.9" if head_dropout else "classifier.8", 256, num_classes)
+    elif name in ("VGG16_BN", "VGG19_BN"):
+        cfg = VGG16_CFG if name == "VGG16_BN" else VGG19_CFG
+        idx, ci = 0, 3
+        for c in cfg:
+            if c == "M":
+                idx += 1
+            else:
+                s.conv(f"features.{idx}", ci, c, 3); s.bn(f"features.{idx + 1}", c); ci = c; idx += 3
+        s.linear("classifier.0", 25088, 4096)
+        s.linear("classifier.3", 4096, 4096)
+        s.linear("classifier.7" if head_dropout else "classifier.6", 4096, num_classes)
     elif name == "ResNetUnet":
         s.conv("encoder1.0", 3, 64, 7, bias=False); s.bn("encoder1.1", 64)
         cin = 64

@@ -14,9 +14,7 @@ from . import nets
 
 CLASSES = ["COVID", "Healthy", "Non-COVID"]          # pipeline.py:22
 
-_FWD = {"AttentionUNet": nets.attention_unet, "R2U_Net": nets.r2u_net, "R2AttU_Net": nets.r2attu_net,
-        "ResNetUnet": nets.resnet_unet, "ResNet18": nets.resnet18, "ResNet50": nets.resnet50,
-        "VGG16": nets.vgg16, "VGG19": nets.vgg19}
+_FWD = nets.NETS
 
 
 @torch.no_grad()

@@ -308,3 +308,77 @@ def test_tester_functions_match_oracle_metrics(capsys):
     pr = np.array([0, 1, 2, 2, 1, 0, 0]); lb = np.array([0, 1, 1, 2, 1, 2, 0])
     cm = tester.calculate_classification_metrics(pr, lb)
     assert abs(cm["accuracy"] - 100 * 5 / 7) < 1e-9 and cm["confusion_matrix"].sum() == 7
+
+
+def _pool_gap(sd64, x):
+    """smallest relative gap between the two largest values of a 2x2 max-pool window (positive maximum) anywhere in
+    the VGG16_BN feature stack, evaluated in fp64"""
+    import torch.nn.functional as F
+    idx, gap, t = 0, 1.0, x.double()
+    for c in nets.VGG16_CFG:
+        if c == "M":
+            n, ch, h, w = t.shape
+            s = t.reshape(n, ch, h // 2, 2, w // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, ch, h // 2, w // 2, 4).sort(-1, descending=True).values
+            gap = min(gap, float(((s[..., 0] - s[..., 1]) / s[..., 0].clamp_min(1e-30))[s[..., 0] > 0].min()))
+            t = F.max_pool2d(t, 2, 2)
+            idx += 1
+        else:
+            t = F.relu(nets._bn(dict(sd64), f"features.{idx + 1}", nets._conv(sd64, f"features.{idx}", t, 1, 1), True))
+            idx += 3
+    return gap
+
+
+def test_vgg16_bn_matches_oracle_fp32():
+    """torchvision-layout vgg16_bn (the model helpers.py:158-166 requests from the hub; config 5's classifier).
+    torchvision is absent, so the check is against the oracle only (parity unpinned at this boundary): eval and
+    train logits, loss, gradients anchored on fp64 like the other nets, BN buffers.  64x64 input -> 2x2 feature
+    map, so AdaptiveAvgPool2d((7,7)) runs its up-sampling branch (overlapping / repeated windows)."""
+    from mi355 import nn as mnn
+    from models.classification_models.VGG import VGG16_BN
+    from utils.helpers import add_dropout_to_fc
+    name = "VGG16_BN"
+    sd = nets.closed_form_state(name, num_classes=3, head_dropout=True)
+    m = VGG16_BN(num_classes=1000)
+    assert add_dropout_to_fc(m, p=0.0) == "classifier"
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    m.load_state_dict(sd)
+    m.compute_dtype = torch.float32
+    m = m.to(DEV)
+    # 260 k max-pool windows: the closest runner-up sits ~1e-7 (relative) below the maximum, and ANY fp32 evaluation
+    # may route that window's gradient to the other element — a valid subgradient, but an O(1e-2) max-norm
+    # difference to fp64 (observed: exactly one flipped window).  Pick, among shifted copies of the closed-form
+    # input, the one whose tightest window is widest, so that the fixture tests arithmetic and not tie-breaking.
+    x0, _ = otrain.closed_form_input(2, 64)
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    cands = [x0.roll((i, j), dims=(2, 3)) for i in range(4) for j in range(4)]
+    gaps = [_pool_gap(sd64, c) for c in cands]
+    x = cands[int(np.argmax(gaps))]
+    assert max(gaps) > 2e-6, gaps
+    y = torch.tensor([1, 2])
+    m.eval()
+    with torch.no_grad():
+        ev = m(x.to(DEV)).cpu()
+        ev_ref = nets.vgg16_bn({k: v.clone() for k, v in sd.items()}, x, False)
+    assert _rel(ev.numpy(), ev_ref.numpy()) < RTOL
+    m.train()
+    out = m(x.to(DEV))
+    loss = mnn.CrossEntropyLoss(label_smoothing=0.1)(out, y.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    l32, o32, g32 = otrain.forward_backward(name, {k: v.clone() for k, v in sd.items()}, x, y, False)
+    l64, o64, g64 = otrain.forward_backward(name, sd64, x.double(), y, False)
+    assert _rel(out.detach().cpu().numpy(), o64.numpy()) < max(RTOL, 4 * _rel(o32.numpy(), o64.numpy()))
+    assert abs(float(loss.detach()) - l64) < RTOL * max(1.0, abs(l64))
+    params = dict(m.named_parameters())
+    gmax = max(float(v.abs().max()) for v in g64.values())
+    e_gpu, e_cpu = [], []
+    for k, ref in g64.items():
+        sc = float(ref.abs().max())
+        if sc < 1e-6 * gmax:
+            continue
+        e_gpu.append(float((params[k].grad.cpu().double() - ref).abs().max()) / sc)
+        e_cpu.append(float((g32[k].double() - ref).abs().max()) / sc)
+    assert np.median(e_gpu) <= max(RTOL, 3 * np.median(e_cpu)), (np.median(e_gpu), np.median(e_cpu))
+    assert np.max(e_gpu) <= max(RTOL, 5 * np.max(e_cpu)), (np.max(e_gpu), np.max(e_cpu))

@@ -16,11 +16,12 @@ def _models():
     from models.segmentation_models.R2AttU_Net import R2AttU_Net
     from models.segmentation_models.R2U_Net import R2U_Net
     from models.classification_models.ResNet import ResNet18, ResNet50
-    from models.classification_models.VGG import VGG16, VGG19
+    from models.classification_models.VGG import VGG16, VGG19, VGG16_BN, VGG19_BN
     return {"AttentionUNet": (AttentionUNet, (2, 3, 32, 32)), "R2AttU_Net": (R2AttU_Net, (1, 3, 32, 32)),
             "R2U_Net": (R2U_Net, (1, 3, 32, 32)), "ResNet18": (lambda: ResNet18(3), (2, 3, 64, 64)),
             "ResNet50": (lambda: ResNet50(3), (2, 3, 64, 64)), "VGG16": (lambda: VGG16(3), (2, 3, 32, 32)),
-            "VGG19": (lambda: VGG19(3), (2, 3, 32, 32))}
+            "VGG19": (lambda: VGG19(3), (2, 3, 32, 32)), "VGG16_BN": (lambda: VGG16_BN(3), (2, 3, 32, 32)),
+            "VGG19_BN": (lambda: VGG19_BN(3), (2, 3, 32, 32))}
 
 
 @pytest.mark.parametrize("name", list(_models()))

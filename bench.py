@@ -159,30 +159,36 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
 
-    from mi355 import nn as mnn, optim as moptim
+    from mi355 import amp as mamp, nn as mnn, optim as moptim
     from mi355.dp import DataParallel
-    from utils.helpers import get_seg_model
+    from utils.helpers import get_class_model, get_seg_model
 
     torch.manual_seed(0)
-    model = get_seg_model({"AttentionUNet": "attentionunet", "R2AttU_Net": "r2attunet", "R2U_Net": "r2unet",
-                           "ResNetUnet": "resnetunet"}[args.model])
+    seg_names = {"AttentionUNet": "attentionunet", "R2AttU_Net": "r2attunet", "R2U_Net": "r2unet", "ResNetUnet": "resnetunet"}
+    seg = args.model in seg_names
+    model = get_seg_model(seg_names[args.model]) if seg else get_class_model(args.model)[0]      # (classifier: stage-2, all layers train)
     model.compute_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
     model = model.to(device).train()
     model.engine._check_storage()
     dp = DataParallel(model, force=args.force_dp) if use_dp else None
-    crit = mnn.BCEWithLogitsLoss()
+    crit = mnn.BCEWithLogitsLoss() if seg else mnn.CrossEntropyLoss(label_smoothing=0.1)
     opt = moptim.AdamW(model.parameters(), lr=1e-6, weight_decay=5e-4)
     inv_scale = dp.inv_scale if dp is not None else 1.0
     opt.inv_scale = inv_scale          # gradient averaging over ranks is folded into clip + AdamW
+    scaler = mamp.GradScaler(enabled=args.dtype == "fp16")      # helpers.py:285,323-336: part of the fp16 step
     x, y = make_batch(args.batch, args.size, seed=rank, device=device)
+    if not seg:
+        y = torch.randint(0, 3, (args.batch,), generator=torch.Generator().manual_seed(rank)).to(device)
 
     def step():
         opt.zero_grad(set_to_none=True)
         out = model(x)
         loss = crit(out, y)
-        loss.backward()
+        scaler.scale(loss).backward()
+        scaler.unscale_(opt)
         moptim.clip_grad_norm_(model.parameters(), max_norm=1.0, inv_scale=inv_scale)
-        opt.step()
+        scaler.step(opt)
+        scaler.update()
         return loss
 
     def log(msg):
@@ -234,14 +240,16 @@ def main():
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.model} {args.size}x{args.size} train step (fwd+BCE+bwd+clip+AdamW), "
+            "config": {"workload": f"{args.model} {args.size}x{args.size} train step (fwd+{'BCE' if seg else 'CE'}+bwd+"
+                                   f"{'unscale+' if args.dtype == 'fp16' else ''}clip+AdamW), "
                                    f"bs={args.batch}/GPU, NHWC {args.dtype} activations, fp32 master weights",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": bool(args.graph),
                        "wgrad_side_stream": os.environ.get("MI355_SIDE_STREAM", "1") != "0",
                        "final_loss": round(final_loss, 5)},
         }
-        step_tflops = TRAIN_GFLOP_PER_IMG * (args.size / 256) ** 2 * value / world / 1e3
-        result["config"]["step_mfma_frac"] = round(step_tflops / PEAK_TFLOPS[args.dtype], 4)
+        if args.model == "AttentionUNet":         # (SURVEY.md 8d gives the per-image FLOPs of this model only)
+            step_tflops = TRAIN_GFLOP_PER_IMG * (args.size / 256) ** 2 * value / world / 1e3
+            result["config"]["step_mfma_frac"] = round(step_tflops / PEAK_TFLOPS[args.dtype], 4)
 
     # ---- per-kernel roofline (instrumented replay of the same plan, rank 0) -----------------------------
     if rank == 0 and not args.no_profile:

@@ -581,13 +581,16 @@ extern "C" int mi355_conv2d_igemm(const void* in, const void* wk, const float* b
   a.Wlog = up ? 2 * Wi : Wi;
   hipStream_t st = (hipStream_t)s;
   const bool k64 = Ci % 64 == 0;
+  const bool wide = Co % 128 == 0 && (long long)(a.M / 256) * (Co / 128) >= 384;
   if (esz == 4) return launch_bn<float, 16>(a, st);
   return dispatch_dtype(dtype, "conv2d_igemm", [&](auto tag) -> int {
     using T = decltype(tag);
     if constexpr (sizeof(T) == 2) {
       switch (v) {
-        case IG_HALO_8x32: return Co % 128 == 0 ? launch_halo<T, 128, 8, 32>(a, st) : launch_halo<T, 64, 8, 32>(a, st);
-        case IG_HALO_16x16: return Co % 128 == 0 ? launch_halo<T, 128, 16, 16>(a, st) : launch_halo<T, 64, 16, 16>(a, st);
+        // 128-wide channel tiles only when they still give >= 1.5 workgroups per CU (two are resident): the deep, small
+        // levels (16x16 images) otherwise leave half of the chip idle
+        case IG_HALO_8x32: return wide ? launch_halo<T, 128, 8, 32>(a, st) : launch_halo<T, 64, 8, 32>(a, st);
+        case IG_HALO_16x16: return wide ? launch_halo<T, 128, 16, 16>(a, st) : launch_halo<T, 64, 16, 16>(a, st);
         case IG_DMA:
           // measured on MI355X (AttentionUNet shapes): the 2-deep BK=64 ring (2 workgroups/CU) wins for 128-wide tiles,
           // the 3-deep BK=32 ring (3-4 workgroups/CU) for 64-wide tiles and for Ci % 64 != 0

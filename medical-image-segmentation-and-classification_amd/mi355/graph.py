@@ -421,7 +421,7 @@ class Builder:
                 self._last_stat_rows = rows
         self.fwd.append(Launch("mi355_conv2d_igemm", x, wf, conv.bias, y, x.N, x.H, x.W, x.C, x.ld, Ho, Wo, Co, y.ld,
                                k, k, s, 1, -p, 1, 1 if up else 0, 0, stat_part, self.code, flops=flops, nbytes=nbytes,
-                               tag=self.igemm_tag(Co, x.C, k, s, Ho, Wo, False, up)))
+                               tag=self.igemm_tag(Co, x.C, k, s, Ho, Wo, False, up, M=x.N * Ho * Wo)))
         y.needs_grad = x.needs_grad or conv.weight.requires_grad
 
         def bwd(dy, bias_done=False):
@@ -440,7 +440,7 @@ class Builder:
                     tmp = self.new_tensor(x.N, 2 * x.H, 2 * x.W, x.C)
                     self.bwd.append(Launch("mi355_conv2d_igemm", dy, wb, None, tmp, x.N, Ho, Wo, Co, dy.ld, 2 * x.H, 2 * x.W,
                                            x.C, tmp.ld, k, k, 1, -1, p, s, 0, 0, None, self.code, flops=flops, nbytes=nbytes,
-                                           tag=self.igemm_tag(x.C, Co, k, s, 2 * x.H, 2 * x.W, True, False)))
+                                           tag=self.igemm_tag(x.C, Co, k, s, 2 * x.H, 2 * x.W, True, False, M=x.N * 4 * x.H * x.W)))
                     acc = self.acc_flag(x)
                     xg = self.grad_of(x)
                     self.bwd.append(Launch("mi355_upsample2_bwd", tmp, tmp.ld, xg, xg.ld, x.N, x.H, x.W, x.C, acc, self.code))
@@ -449,19 +449,20 @@ class Builder:
                     xg = self.grad_of(x)
                     self.bwd.append(Launch("mi355_conv2d_igemm", dy, wb, None, xg, x.N, Ho, Wo, Co, dy.ld, x.H, x.W, x.C,
                                            xg.ld, k, k, 1, -1, p, s, 0, acc, None, self.code, flops=flops, nbytes=nbytes,
-                                           tag=self.igemm_tag(x.C, Co, k, s, x.H, x.W, True, False)))
+                                           tag=self.igemm_tag(x.C, Co, k, s, x.H, x.W, True, False, M=x.N * x.H * x.W)))
         return y, bwd
 
-    def igemm_tag(self, co, ci, k=1, s=1, Ho=0, Wo=0, dgrad=False, up=False):
+    def igemm_tag(self, co, ci, k=1, s=1, Ho=0, Wo=0, dgrad=False, up=False, M=0):
         """Kernel variant mi355_conv2d_igemm dispatches to (mirrors the launcher in csrc/conv_igemm.hip)."""
         bn = 128 if co % 128 == 0 else (64 if co % 64 == 0 else 32)
         if self.dtype == torch.float32:
             return f"conv_igemm_kernel<f32,{bn},16>"
         if k == 3 and s == 1 and co % 64 == 0 and not (dgrad and up):
+            hb = 128 if (bn == 128 and (M // 256) * (co // 128) >= 384) else 64      # narrow tiles on small grids
             if Wo % 32 == 0 and Ho % 8 == 0:
-                return f"conv3x3_halo_kernel<{min(bn, 128)},8,32>"
+                return f"conv3x3_halo_kernel<{hb},8,32>"
             if Wo % 16 == 0 and Ho % 16 == 0:
-                return f"conv3x3_halo_kernel<{min(bn, 128)},16,16>"
+                return f"conv3x3_halo_kernel<{hb},16,16>"
         k64 = ci % 64 == 0
         if bn == 128:
             return "conv_igemm_dma_kernel<128,64,2>" if k64 else "conv_igemm_dma_kernel<128,32,3>"

@@ -6,6 +6,7 @@
 // ---- forward statistics --------------------------------------------------------------------------
 template <typename T> struct BnStatsOp {
   static constexpr int NQ = 2;
+  static constexpr bool WRITES = false;
   typedef double Acc;
   static constexpr int EPC = 16 / (int)sizeof(T);
   const T* x;
@@ -191,6 +192,7 @@ extern "C" int mi355_bn_act(const void* x, int ldx, const float* scale, const fl
 // ---- backward ------------------------------------------------------------------------------------
 template <typename T> struct BnBwdReduceOp {
   static constexpr int NQ = 2;
+  static constexpr bool WRITES = false;
   typedef float Acc;
   static constexpr int EPC = 16 / (int)sizeof(T);
   const T* dy; int lddy; const T* y; int ldy; const T* x; int ldx;
@@ -259,6 +261,7 @@ extern "C" int mi355_bn_bwd_finalize(const float* partial, int nblocks, int C, f
 
 template <typename T> struct BnBwdApplyOp {
   static constexpr int NQ = 1;
+  static constexpr bool WRITES = true;
   typedef float Acc;
   static constexpr int EPC = 16 / (int)sizeof(T);
   const T* dy; int lddy; const T* y; int ldy; const T* x; int ldx;
@@ -320,6 +323,7 @@ extern "C" int mi355_bn_bwd_apply(const void* dy, int lddy, const void* y, int l
 // ---- plain column sums (bias gradients) -------------------------------------------------------------
 template <typename T> struct ColSumOp {
   static constexpr int NQ = 1;
+  static constexpr bool WRITES = false;
   typedef float Acc;
   static constexpr int EPC = 16 / (int)sizeof(T);
   const T* x; int ld;

@@ -99,6 +99,7 @@ extern "C" int mi355_rowdot_fwd(const void* x, int ldx, const float* w, const fl
 // dx[m][c] = dz[m]*w[c]*(mask ? x[m][c] > 0 : 1);  partial: q0 = sum_m dz[m]*x[m][c], q1 = sum_m dz[m]
 template <typename T> struct RowdotBwdOp {
   static constexpr int NQ = 2;
+  static constexpr bool WRITES = true;
   typedef float Acc;
   static constexpr int EPC = 16 / (int)sizeof(T);
   const float* dz; const T* x; int ldx; const float* w; T* dx; int lddx; int mask;

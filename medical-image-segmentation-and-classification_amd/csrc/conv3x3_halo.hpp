@@ -260,3 +260,263 @@ static int launch_halo(const ConvArgs& a, hipStream_t s) {
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }
+
+// ---- 64-channel-wide variant with a patch-row register window ----------------------------------------------------
+// Used when Co is not a multiple of 128 or the 128-wide grid would leave compute units idle.  Wave tile = 128 pixels
+// (RW tile rows) x 32 channels, 64 accumulator registers per lane.  The K loop runs over (32-channel chunk, patch
+// COLUMN shift pw): for one pw the three taps of that column are resident together (three 4-KiB weight slabs per ring
+// stage), and a patch-row fragment is read from LDS ONCE and multiplied into the up to three output rows it serves
+// (patch row offsets ph = 0, 1, 2): (RW + 2) * XB pixel-fragment reads + 6 weight-fragment reads per 48 MFMAs and
+// one workgroup barrier per 48 MFMAs per wave — the tap-by-tap kernel above needs 24 reads and three barriers for
+// the same work at this tile width.
+template <int TH, int TW> struct HaloRwCfg {
+  static constexpr int BN = 64;
+  static constexpr int NPIX = (TH + 2) * (TW + 2);
+  static constexpr int P_INSTR = (NPIX + 15) / 16;               // 1-KiB DMA instructions per patch; the buffers are packed
+  static constexpr int PATCH_BYTES = P_INSTR * 1024;
+  static constexpr int STAGE_BYTES = 3 * BN * 64;                // three taps of one patch column
+  static constexpr int NS = 3;
+  static constexpr int RING = 2 * PATCH_BYTES + NS * STAGE_BYTES;
+  static constexpr int C_BYTES = TH * TW * (BN * 2 + 16);
+  static constexpr int EPI_BYTES = C_BYTES + 2 * 2 * BN * 4;     // C tile + statistics scratch [WM = 2][2][BN]
+  static constexpr int LDS_BYTES = RING > EPI_BYTES ? RING : EPI_BYTES;
+};
+
+template <typename T, int TH, int TW>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_rw_kernel(const ConvArgs a) {
+  static_assert(sizeof(T) == 2, "bf16 / fp16 only");
+  typedef HaloRwCfg<TH, TW> Cfg;
+  constexpr int BN = 64, BK = 32, EPC = 8, BM = TH * TW;
+  static_assert(BM == 256 && TW % 16 == 0, "tile must hold 256 pixels in rows of 16-pixel blocks");
+  constexpr int PH = TH + 2, PW = TW + 2, NPIX = PH * PW;
+  constexpr int PIXB = BK * 2;                       // 64 B per pixel / weight row
+  constexpr int P_INSTR = Cfg::P_INSTR;
+  constexpr int P_IT = (P_INSTR + 3) / 4;            // per wave (the last round may be short: see p_it)
+  constexpr int PATCH_BYTES = Cfg::PATCH_BYTES;
+  constexpr int SLAB = BN * PIXB, STAGE = Cfg::STAGE_BYTES, NS = Cfg::NS;
+  constexpr int B_IT = 3;                            // DMA instructions per wave per stage: 3 slabs x 4 KiB / 4 waves
+  constexpr int WM = 2, WN = 2, WTM = BM / WM, WTN = BN / WN;
+  constexpr int RW = WTM / TW, XB = TW / 16;         // tile rows per wave, 16-pixel blocks per row
+  constexpr int MB = RW * XB, NB = WTN / 16;         // 8 x 2 MFMA blocks of 16x16 per wave
+  constexpr int C_PITCH = BN * 2 + 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l16 = lane & 15, c4 = lane >> 4;
+  const int wm = wave / WN, wn = wave % WN;
+  const int NT = a.Co / BN, TXN = a.Wo / TW, TYN = a.Ho / TH;
+  const int bid = xcd_tile(blockIdx.x, gridDim.x);
+  int t = bid;
+  const int nt = t % NT; t /= NT;
+  const int tx = t % TXN; t /= TXN;
+  const int ty = t % TYN;
+  const int n = t / TYN;
+  const int y0 = ty * TH, x0 = tx * TW, n0 = nt * BN;
+  const T* __restrict__ in = reinterpret_cast<const T*>(a.in);
+  const T* __restrict__ wk = reinterpret_cast<const T*>(a.wk);
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+  const bool flip = a.kmul < 0;                      // data gradient: taps mirrored
+
+  // ---- DMA lane geometry (as in conv3x3_halo_kernel; a wave issues instruction wave + 4*i while it is < P_INSTR) ----
+  const int lrow = lane >> 2, slot = lane & 3;
+  const bool short_last = wave + 4 * (P_IT - 1) >= P_INSTR;       // this wave issues P_IT - 1 patch instructions
+  const T* p_src[P_IT];
+#pragma unroll
+  for (int i = 0; i < P_IT; ++i) {
+    const int q = (wave + 4 * i) * 16 + lrow;
+    const int py = q / PW, px = q - py * PW;
+    const int yy = y0 - 1 + py, xx = x0 - 1 + px;
+    const bool ok = q < NPIX && (unsigned)yy < (unsigned)a.Hlog && (unsigned)xx < (unsigned)a.Wlog;
+    p_src[i] = ok ? in + ((size_t)(n * a.Hi + (yy >> a.up)) * a.Wi + (xx >> a.up)) * a.ldi + (slot ^ (((q >> 2) & 1) << 1)) * EPC
+                  : nullptr;
+  }
+  unsigned char* const patch0 = lds;
+  unsigned char* const bring = lds + 2 * PATCH_BYTES;
+  auto issue_patch = [&](int buf, int c0) {
+    unsigned char* dst = patch0 + buf * PATCH_BYTES;
+#pragma unroll
+    for (int i = 0; i < P_IT; ++i) {
+      if (i == P_IT - 1 && short_last) break;
+      const char* p = p_src[i] ? reinterpret_cast<const char*>(p_src[i] + c0) : zero + slot * 16;
+      dma16(p, lds_addr(dst + (wave + 4 * i) * 1024));
+    }
+  };
+  // stage = the three taps of patch column pw: slab ph holds tap (ph, pw), mirrored for the data gradient; a wave
+  // brings 16 rows x 64 B of each slab (one instruction per slab)
+  const size_t wrow = (size_t)9 * a.Ci;
+  const int brow = wave * 16 + lrow;
+  const T* const b_src = wk + (size_t)(n0 + brow) * wrow + (slot ^ (((brow >> 2) & 1) << 1)) * EPC;
+  auto issue_stage = [&](int stage, int pw, int c0) {
+    unsigned char* dst = bring + stage * STAGE + wave * 1024;
+#pragma unroll
+    for (int ph = 0; ph < 3; ++ph) {
+      const int tap = flip ? (2 - ph) * 3 + (2 - pw) : ph * 3 + pw;
+      dma16(b_src + (size_t)tap * a.Ci + c0, lds_addr(dst + ph * SLAB));
+    }
+  };
+
+  // ---- fragment geometry ------------------------------------------------------------------------------------------
+  const int q00 = (wm * RW) * PW + l16;              // patch pixel of (first wave row, x = l16, column shift 0)
+  int boff[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int row = wn * WTN + nb * 16 + l16;
+    boff[nb] = row * PIXB + ((c4 ^ (((row >> 2) & 1) << 1)) << 4);
+  }
+  f32x4 acc[MB][NB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nC = a.Ci / BK;
+  const int S = nC * 3;                              // steps = (chunk, patch column)
+  int ipw = 0, ic0 = 0, issued = 0, istage = 0;
+  auto issue_next = [&]() {
+    issue_stage(istage, ipw, ic0);
+    istage = (istage + 1 == NS) ? 0 : istage + 1;
+    if (++ipw == 3) {
+      ipw = 0;
+      ic0 += BK;
+    }
+    ++issued;
+  };
+  issue_patch(0, 0);
+  issue_next();
+  issue_next();                                      // S >= 3
+  wait_vmcnt<B_IT>();
+  __builtin_amdgcn_s_barrier();
+
+  int stage = 0, pw = 0, chunk = 0;
+  for (int s = 0; s < S; ++s) {
+    const bool more_b = issued < S;
+    if (more_b) issue_next();
+    const bool patch_now = pw == 0 && chunk + 1 < nC;
+    if (patch_now) issue_patch((chunk + 1) & 1, (chunk + 1) * BK);
+
+    const unsigned char* pa = patch0 + (chunk & 1) * PATCH_BYTES;
+    const unsigned char* pb = bring + stage * STAGE;
+    bf16x8 bfr[3][NB];
+#pragma unroll
+    for (int ph = 0; ph < 3; ++ph)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) bfr[ph][nb] = *reinterpret_cast<const bf16x8*>(pb + ph * SLAB + boff[nb]);
+    bf16x8 afr[RW + 2][XB];
+#pragma unroll
+    for (int pr = 0; pr < RW + 2; ++pr)
+#pragma unroll
+      for (int xb = 0; xb < XB; ++xb) {
+        const int q = q00 + pr * PW + xb * 16 + pw;
+        afr[pr][xb] = *reinterpret_cast<const bf16x8*>(pa + q * PIXB + ((c4 ^ (((q >> 2) & 1) << 1)) << 4));
+      }
+#pragma unroll
+    for (int pr = 0; pr < RW + 2; ++pr)
+#pragma unroll
+      for (int xb = 0; xb < XB; ++xb)
+#pragma unroll
+        for (int ph = 0; ph < 3; ++ph) {
+          const int orow = pr - ph;                    // output row of this wave served through patch-row offset ph
+          if (orow >= 0 && orow < RW) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+              acc[orow * XB + xb][nb] = mfma_16x16x32<T>(afr[pr][xb], bfr[ph][nb], acc[orow * XB + xb][nb]);
+          }
+        }
+    // registers are plentiful at this tile width (64 accumulators): every fragment read of the step is issued first,
+    // the 48 MFMAs then wait with counted lgkmcnt for exactly the operands they need (+2 % over the compiler's order)
+    __builtin_amdgcn_sched_group_barrier(0x100, 3 * NB + (RW + 2) * XB, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 3 * NB * RW * XB, 0);
+    // stage s+1 (and, in order before it, any older patch) must have landed; what may stay in flight: the stage
+    // issued this step and a patch issued this step or the one before
+    const bool patch_pending = (pw <= 1) && chunk + 1 < nC;
+    if (more_b) {
+      if (patch_pending) {
+        if (short_last) wait_vmcnt<B_IT + P_IT - 1>(); else wait_vmcnt<B_IT + P_IT>();
+      } else {
+        wait_vmcnt<B_IT>();
+      }
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    stage = (stage + 1 == NS) ? 0 : stage + 1;
+    if (++pw == 3) {
+      pw = 0;
+      ++chunk;
+    }
+  }
+
+  // ---- epilogue (as conv3x3_halo_kernel) ------------------------------------------------------------------------------
+  T* __restrict__ out = reinterpret_cast<T*>(a.out);
+  float bcol[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) bcol[nb] = a.bias ? a.bias[n0 + wn * WTN + nb * 16 + l16] : 0.f;
+  float* const red = reinterpret_cast<float*>(lds + Cfg::C_BYTES);      // [WM][2][BN] behind the C tile
+  if (a.stats) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      float sm = 0.f, sq = 0.f;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = to_f32<T>(from_f32<T>(acc[mb][nb][r] + bcol[nb]));
+          sm += v;
+          sq += v * v;
+        }
+      sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);
+      sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
+      if (c4 == 0) {
+        red[(wm * 2 + 0) * BN + wn * WTN + nb * 16 + l16] = sm;
+        red[(wm * 2 + 1) * BN + wn * WTN + nb * 16 + l16] = sq;
+      }
+    }
+  }
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wm * WTM + mb * 16 + c4 * 4 + r;
+        const int col = wn * WTN + nb * 16 + l16;
+        *reinterpret_cast<T*>(lds + row * C_PITCH + col * 2) = from_f32<T>(acc[mb][nb][r] + bcol[nb]);
+      }
+  __syncthreads();
+  if (a.stats && tid < 2 * BN) {
+    const int q = tid / BN, c = tid - q * BN;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < WM; ++w) v += red[(w * 2 + q) * BN + c];
+    a.stats[((size_t)(bid / NT) * 2 + q) * a.Co + n0 + c] = v;
+  }
+  constexpr int CPRC = BN / EPC;
+  for (int id = tid; id < BM * CPRC; id += 256) {
+    const int row = id / CPRC, c = id - row * CPRC;
+    const int py = row / TW, px = row - py * TW;
+    T* p = out + ((size_t)(n * a.Ho + y0 + py) * a.Wo + x0 + px) * a.ldo + n0 + c * EPC;
+    Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(lds + row * C_PITCH + c * 16);
+    if (a.accumulate) {
+      const Vec16<T> o = ld16<T>(p);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) v.v[e] = from_f32<T>(to_f32<T>(v.v[e]) + to_f32<T>(o.v[e]));
+    }
+    st16<T>(p, v);
+  }
+}
+
+template <typename T, int TH, int TW>
+static int launch_halo_rw(const ConvArgs& a, hipStream_t s) {
+  const int grid = a.N * (a.Ho / TH) * (a.Wo / TW) * (a.Co / 64);
+  constexpr int lds_bytes = HaloRwCfg<TH, TW>::LDS_BYTES;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_rw_kernel<T, TH, TW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       lds_bytes);
+    if (e != hipSuccess) MI355_FAIL((int)e, "conv3x3_halo_rw: cannot reserve %d B of LDS: %s", lds_bytes, hipGetErrorString(e));
+    configured = true;
+  }
+  hipLaunchKernelGGL((conv3x3_halo_rw_kernel<T, TH, TW>), dim3(grid), dim3(256), lds_bytes, s, a);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}

@@ -1,274 +1,32 @@
-// 3x3 / stride-1 / pad-1 convolution (forward and data gradient) for bf16 on gfx950:
-// implicit GEMM with a HALO-PATCH A operand.
+// 3x3 / stride-1 / pad-1 convolution (forward and data gradient) for bf16 / fp16 on gfx950:
+// implicit GEMM with a HALO-PATCH A operand and a patch-row register window.
 //
-// A workgroup owns a TH x TW spatial tile (256 pixels) of one image times BN output channels.
+// A workgroup owns a TH x TW spatial tile (256 pixels) of one image times 64 output channels.
 // For every 32-channel slab of Ci the (TH+2) x (TW+2) input patch is streamed into LDS ONCE by
 // LDS-DMA and then serves all nine taps (the tap only shifts the fragment read address), so the
-// activation is fetched ~1.3x instead of 9x per K sweep; only the [BN][32] weight slab of each tap
-// is re-streamed (3-deep ring, counted s_waitcnt vmcnt across raw s_barriers).  L2->LDS traffic per
-// MFMA drops ~3x versus the im2col-style gather, DMA-issue and address VALU per MFMA ~3x.
+// activation is fetched ~1.3x instead of 9x per K sweep; the weight slabs of the three taps of one patch
+// COLUMN travel together through a 3-stage ring (counted s_waitcnt vmcnt across raw s_barriers).
 //   (nearest x2 up-sampling of the input is folded into the patch gather: source pixel = logical >> 1)
-// (s_setprio(1) around the MFMA cluster was measured: -3 % with two 4-wave workgroups per CU — not used.)
 //   MFMA        : v_mfma_f32_16x16x32_bf16 / _f16 — one instruction consumes a whole 32-deep slab of a 16x16 block;
 //                 at equal operand traffic it ran 8 % faster in situ than 32x32x16 (the chip holds a higher
 //                 clock on this shape, MI355X_MICROARCH.md DVFS item 7)
 //   patch image : pixel-linear, 64 B per pixel, 16-B chunk slot = chunk ^ (((pixel >> 2) & 1) << 1)
 //                 (source-side swizzle; conflict-free ds_read_b128 for the 16x16x32 operand map — 16 consecutive
 //                 pixels x 4 k-chunks per wave-instruction — at ANY pixel alignment, i.e. for all nine tap shifts)
-//   weight slab : [BN rows][64 B], same slot rule on the row index
+//   weight slab : [64 rows][64 B], same slot rule on the row index
+// History: a tap-by-tap version of this kernel (one weight slab and one barrier per tap, 128- or
+// 64-wide) was the round's dominant kernel at 1100 TFLOP/s; the patch-row window below replaced it at +5-8 % on
+// the same layers (+19 % on the 64-wide ones).
 #pragma once
 #include "common.hpp"
 
-template <int BN, int TH, int TW> struct HaloCfg {
-  static constexpr int NPIX = (TH + 2) * (TW + 2);
-  static constexpr int P_IT = ((NPIX + 15) / 16 + 3) / 4;
-  static constexpr int PATCH_BYTES = P_IT * 4 * 1024;
-  static constexpr int RING = 2 * PATCH_BYTES + 3 * BN * 64;
-  static constexpr int C_BYTES = TH * TW * (BN * 2 + 16);
-  static constexpr int EPI_BYTES = C_BYTES + 4 * 2 * BN * 4;     // C tile + statistics scratch [WM<=4][2][BN]
-  static constexpr int LDS_BYTES = RING > EPI_BYTES ? RING : EPI_BYTES;
-};
-
-template <typename T, int BN, int TH, int TW>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvArgs a) {
-  static_assert(sizeof(T) == 2, "bf16 / fp16 only");
-  constexpr int BK = 32, EPC = 8, BM = TH * TW;
-  static_assert(BM == 256, "tile must hold 256 pixels");
-  constexpr int PH = TH + 2, PW = TW + 2, NPIX = PH * PW;
-  constexpr int PIXB = BK * 2;                       // 64 B per pixel / weight row
-  constexpr int P_INSTR = (NPIX + 15) / 16;          // 1-KiB DMA instructions per patch
-  constexpr int P_IT = (P_INSTR + 3) / 4;            // per wave
-  constexpr int PATCH_BYTES = P_IT * 4 * 1024;
-  constexpr int B_IT = BN / 16 / 4;                  // DMA instructions per wave per weight slab
-  constexpr int B_BYTES = BN * PIXB;
-  constexpr int NSB = 3;
-  constexpr int WM = (BN == 128) ? 2 : 4, WN = 4 / WM;
-  constexpr int WTM = BM / WM, WTN = BN / WN;
-  constexpr int MB = WTM / 16, NB = WTN / 16;          // 16x16 MFMA blocks per wave tile
-  constexpr int C_PITCH = BN * 2 + 16;
-  static_assert(HaloCfg<BN, TH, TW>::PATCH_BYTES == PATCH_BYTES && NSB == 3, "host/device LDS layout mismatch");
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // HaloCfg::LDS_BYTES (> 64 KiB: dynamic)
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l16 = lane & 15, c4 = lane >> 4;           // 16x16x32 operand map: row/col l16, k-chunk c4 (8 bf16 each)
-  const int wm = wave / WN, wn = wave % WN;
-  const int NT = a.Co / BN, TXN = a.Wo / TW, TYN = a.Ho / TH;     // tiles walk the OUTPUT grid (= input grid, x2 if `up`)
-  const int bid = xcd_tile(blockIdx.x, gridDim.x);
-  int t = bid;
-  const int nt = t % NT; t /= NT;
-  const int tx = t % TXN; t /= TXN;
-  const int ty = t % TYN;
-  const int n = t / TYN;
-  const int y0 = ty * TH, x0 = tx * TW, n0 = nt * BN;
-  const T* __restrict__ in = reinterpret_cast<const T*>(a.in);
-  const T* __restrict__ wk = reinterpret_cast<const T*>(a.wk);
-  const char* zero = reinterpret_cast<const char*>(g_zero_page);
-  const bool flip = a.kmul < 0;                      // data gradient: taps mirrored
-
-  // ---- DMA lane geometry ----------------------------------------------------------------------
-  const int lrow = lane >> 2, slot = lane & 3;
-  const T* p_src[P_IT];                              // per-lane source of each patch instruction (chunk applied)
-#pragma unroll
-  for (int i = 0; i < P_IT; ++i) {
-    const int q = (wave + 4 * i) * 16 + lrow;        // patch pixel index
-    const int py = q / PW, px = q - py * PW;
-    const int yy = y0 - 1 + py, xx = x0 - 1 + px;          // on the logical (post-upsample) grid
-    const bool ok = q < NPIX && (unsigned)yy < (unsigned)a.Hlog && (unsigned)xx < (unsigned)a.Wlog;
-    p_src[i] = ok ? in + ((size_t)(n * a.Hi + (yy >> a.up)) * a.Wi + (xx >> a.up)) * a.ldi + (slot ^ (((q >> 2) & 1) << 1)) * EPC
-                  : nullptr;
-  }
-  const size_t wrow = (size_t)9 * a.Ci;
-  const T* b_src[B_IT];
-#pragma unroll
-  for (int i = 0; i < B_IT; ++i) {
-    const int row = (wave + 4 * i) * 16 + lrow;
-    b_src[i] = wk + (size_t)(n0 + row) * wrow + (slot ^ (((row >> 2) & 1) << 1)) * EPC;
-  }
-  unsigned char* const patch0 = lds;
-  unsigned char* const bring = lds + 2 * PATCH_BYTES;
-
-  auto issue_patch = [&](int buf, int c0) {
-    unsigned char* dst = patch0 + buf * PATCH_BYTES;
-#pragma unroll
-    for (int i = 0; i < P_IT; ++i) {
-      const char* p = p_src[i] ? reinterpret_cast<const char*>(p_src[i] + c0) : zero + slot * 16;
-      dma16(p, lds_addr(dst + (wave + 4 * i) * 1024));
-    }
-  };
-  auto issue_b = [&](int stage, int tap, int c0) {
-    unsigned char* dst = bring + stage * B_BYTES;
-    const size_t off = (size_t)tap * a.Ci + c0;
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) dma16(b_src[i] + off, lds_addr(dst + (wave + 4 * i) * 1024));
-  };
-
-  // ---- fragment geometry ------------------------------------------------------------------------
-  int q0[MB];                                        // patch pixel of (tile pixel, tap (0,0))
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
-    const int p = wm * WTM + mb * 16 + l16;
-    const int py = p / TW, px = p - py * TW;
-    q0[mb] = py * PW + px;
-  }
-  int boff[NB];                                      // byte offset of this lane's fragment inside a weight slab
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    const int row = wn * WTN + nb * 16 + l16;
-    boff[nb] = row * PIXB + ((c4 ^ (((row >> 2) & 1) << 1)) << 4);
-  }
-
-  f32x4 acc[MB][NB];
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nC = a.Ci / BK;
-  const int S = nC * 9;
-  // issue-side iterator for weight slabs
-  int itap = 0, ic0 = 0, issued = 0, istage = 0;
-  auto issue_next_b = [&]() {
-    issue_b(istage, itap, ic0);
-    istage = (istage + 1 == NSB) ? 0 : istage + 1;
-    if (++itap == 9) {
-      itap = 0;
-      ic0 += BK;
-    }
-    ++issued;
-  };
-  issue_patch(0, 0);
-  issue_next_b();
-  if (S > 1) {
-    issue_next_b();
-    wait_vmcnt<B_IT>();
-  } else {
-    wait_vmcnt<0>();
-  }
-  __builtin_amdgcn_s_barrier();
-
-  int stage = 0, tap = 0, chunk = 0;
-  for (int s = 0; s < S; ++s) {
-    const bool more_b = issued < S;
-    if (more_b) issue_next_b();
-    const bool patch_now = tap == 0 && chunk + 1 < nC;
-    if (patch_now) issue_patch((chunk + 1) & 1, (chunk + 1) * BK);
-
-    const unsigned char* pa = patch0 + (chunk & 1) * PATCH_BYTES;
-    const unsigned char* pb = bring + stage * B_BYTES;
-    const int kh = tap / 3, kw = tap - kh * 3;
-    const int toff = flip ? (2 - kh) * PW + (2 - kw) : kh * PW + kw;
-    {   // one 32-deep slab = one v_mfma_f32_16x16x32_bf16 per (pixel block, channel block)
-      bf16x8 bfr[NB];
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) bfr[nb] = *reinterpret_cast<const bf16x8*>(pb + boff[nb]);
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        const int q = q0[mb] + toff;
-        const bf16x8 af = *reinterpret_cast<const bf16x8*>(pa + q * PIXB + ((c4 ^ (((q >> 2) & 1) << 1)) << 4));
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = mfma_16x16x32<T>(af, bfr[nb], acc[mb][nb]);
-      }
-    }
-    // the next slab (and, in order before it, any older patch) must have landed; what may stay in
-    // flight: the slab issued this step and a patch issued this step or the one before
-    const bool patch_pending = (tap <= 1) && chunk + 1 < nC;
-    if (more_b) {
-      if (patch_pending) wait_vmcnt<B_IT + P_IT>(); else wait_vmcnt<B_IT>();
-    } else {
-      wait_vmcnt<0>();
-    }
-    __builtin_amdgcn_s_barrier();
-    stage = (stage + 1 == NSB) ? 0 : stage + 1;
-    if (++tap == 9) {
-      tap = 0;
-      ++chunk;
-    }
-  }
-
-  // ---- epilogue ------------------------------------------------------------------------------------
-  T* __restrict__ out = reinterpret_cast<T*>(a.out);
-  float bcol[NB];
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) bcol[nb] = a.bias ? a.bias[n0 + wn * WTN + nb * 16 + l16] : 0.f;
-  float* const red = reinterpret_cast<float*>(lds + HaloCfg<BN, TH, TW>::C_BYTES);      // [WM][2][BN] behind the C tile
-  if (a.stats) {        // fused BatchNorm statistics of the ROUNDED outputs this tile stores
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      float sm = 0.f, sq = 0.f;
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v = to_f32<T>(from_f32<T>(acc[mb][nb][r] + bcol[nb]));
-          sm += v;
-          sq += v * v;
-        }
-      sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);      // fold the four row groups (lane >> 4)
-      sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
-      if (c4 == 0) {
-        red[(wm * 2 + 0) * BN + wn * WTN + nb * 16 + l16] = sm;
-        red[(wm * 2 + 1) * BN + wn * WTN + nb * 16 + l16] = sq;
-      }
-    }
-  }
-  // C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = wm * WTM + mb * 16 + c4 * 4 + r;
-        const int col = wn * WTN + nb * 16 + l16;
-        *reinterpret_cast<T*>(lds + row * C_PITCH + col * 2) = from_f32<T>(acc[mb][nb][r] + bcol[nb]);
-      }
-  __syncthreads();
-  if (a.stats && tid < 2 * BN) {
-    const int q = tid / BN, c = tid - q * BN;
-    float v = 0.f;
-#pragma unroll
-    for (int w = 0; w < WM; ++w) v += red[(w * 2 + q) * BN + c];
-    a.stats[((size_t)(bid / NT) * 2 + q) * a.Co + n0 + c] = v;
-  }
-  constexpr int CPRC = BN / EPC;
-  for (int id = tid; id < BM * CPRC; id += 256) {
-    const int row = id / CPRC, c = id - row * CPRC;
-    const int py = row / TW, px = row - py * TW;
-    T* p = out + ((size_t)(n * a.Ho + y0 + py) * a.Wo + x0 + px) * a.ldo + n0 + c * EPC;
-    Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(lds + row * C_PITCH + c * 16);
-    if (a.accumulate) {
-      const Vec16<T> o = ld16<T>(p);
-#pragma unroll
-      for (int e = 0; e < EPC; ++e) v.v[e] = from_f32<T>(to_f32<T>(v.v[e]) + to_f32<T>(o.v[e]));
-    }
-    st16<T>(p, v);
-  }
-}
-
-template <typename T, int BN, int TH, int TW>
-static int launch_halo(const ConvArgs& a, hipStream_t s) {
-  const int grid = a.N * (a.Ho / TH) * (a.Wo / TW) * (a.Co / BN);
-  constexpr int lds_bytes = HaloCfg<BN, TH, TW>::LDS_BYTES;
-  static bool configured = false;        // immutable after the first call (set before any launch of this variant)
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, BN, TH, TW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       lds_bytes);
-    if (e != hipSuccess) MI355_FAIL((int)e, "conv3x3_halo: cannot reserve %d B of LDS: %s", lds_bytes, hipGetErrorString(e));
-    configured = true;
-  }
-  hipLaunchKernelGGL((conv3x3_halo_kernel<T, BN, TH, TW>), dim3(grid), dim3(256), lds_bytes, s, a);
-  MI355_LAUNCH_CHECK();
-  return MI355_OK;
-}
-
-// ---- 64-channel-wide variant with a patch-row register window ----------------------------------------------------
-// Used when Co is not a multiple of 128 or the 128-wide grid would leave compute units idle.  Wave tile = 128 pixels
+// ---- patch-row register window -------------------------------------------------------------------------------------
+// Wave tile = 128 pixels
 // (RW tile rows) x 32 channels, 64 accumulator registers per lane.  The K loop runs over (32-channel chunk, patch
 // COLUMN shift pw): for one pw the three taps of that column are resident together (three 4-KiB weight slabs per ring
 // stage), and a patch-row fragment is read from LDS ONCE and multiplied into the up to three output rows it serves
 // (patch row offsets ph = 0, 1, 2): (RW + 2) * XB pixel-fragment reads + 6 weight-fragment reads per 48 MFMAs and
-// one workgroup barrier per 48 MFMAs per wave — the tap-by-tap kernel above needs 24 reads and three barriers for
-// the same work at this tile width.
+// one workgroup barrier per 48 MFMAs per wave (tap by tap: 24 reads and three barriers for the same work).
 template <int TH, int TW> struct HaloRwCfg {
   static constexpr int BN = 64;
   static constexpr int NPIX = (TH + 2) * (TW + 2);
@@ -317,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_rw_kernel(const ConvArgs 
   const char* zero = reinterpret_cast<const char*>(g_zero_page);
   const bool flip = a.kmul < 0;                      // data gradient: taps mirrored
 
-  // ---- DMA lane geometry (as in conv3x3_halo_kernel; a wave issues instruction wave + 4*i while it is < P_INSTR) ----
+  // ---- DMA lane geometry: a 1-KiB instruction = 16 patch pixels x 64 B; a wave issues instruction wave + 4*i while it is < P_INSTR ----
   const int lrow = lane >> 2, slot = lane & 3;
   const bool short_last = wave + 4 * (P_IT - 1) >= P_INSTR;       // this wave issues P_IT - 1 patch instructions
   const T* p_src[P_IT];
@@ -446,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_rw_kernel(const ConvArgs 
     }
   }
 
-  // ---- epilogue (as conv3x3_halo_kernel) ------------------------------------------------------------------------------
+  // ---- epilogue: bias, fused BN partial sums of the ROUNDED outputs, C tile staged through LDS for 16-B row-contiguous stores ----
   T* __restrict__ out = reinterpret_cast<T*>(a.out);
   float bcol[NB];
 #pragma unroll

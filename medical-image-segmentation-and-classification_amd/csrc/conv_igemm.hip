@@ -581,21 +581,13 @@ extern "C" int mi355_conv2d_igemm(const void* in, const void* wk, const float* b
   a.Wlog = up ? 2 * Wi : Wi;
   hipStream_t st = (hipStream_t)s;
   const bool k64 = Ci % 64 == 0;
-  static const int halo_rw = getenv("MI355_HALO_RW") ? atoi(getenv("MI355_HALO_RW")) : 1;
-  const bool wide = Co % 128 == 0 && (long long)(a.M / 256) * (Co / 128) >= 384;
   if (esz == 4) return launch_bn<float, 16>(a, st);
   return dispatch_dtype(dtype, "conv2d_igemm", [&](auto tag) -> int {
     using T = decltype(tag);
     if constexpr (sizeof(T) == 2) {
       switch (v) {
-        // 128-wide channel tiles only when they still give >= 1.5 workgroups per CU (two are resident): the deep, small
-        // levels (16x16 images) otherwise leave half of the chip idle
-        case IG_HALO_8x32:
-          if (wide) return launch_halo<T, 128, 8, 32>(a, st);
-          return halo_rw ? launch_halo_rw<T, 8, 32>(a, st) : launch_halo<T, 64, 8, 32>(a, st);
-        case IG_HALO_16x16:
-          if (wide) return launch_halo<T, 128, 16, 16>(a, st);
-          return halo_rw ? launch_halo_rw<T, 16, 16>(a, st) : launch_halo<T, 64, 16, 16>(a, st);
+        case IG_HALO_8x32: return launch_halo_rw<T, 8, 32>(a, st);
+        case IG_HALO_16x16: return launch_halo_rw<T, 16, 16>(a, st);
         case IG_DMA:
           // measured on MI355X (AttentionUNet shapes): the 2-deep BK=64 ring (2 workgroups/CU) wins for 128-wide tiles,
           // the 3-deep BK=32 ring (3-4 workgroups/CU) for 64-wide tiles and for Ci % 64 != 0

@@ -458,12 +458,10 @@ class Builder:
         if self.dtype == torch.float32:
             return f"conv_igemm_kernel<f32,{bn},16>"
         if k == 3 and s == 1 and co % 64 == 0 and not (dgrad and up):
-            hb = 128 if (bn == 128 and (M // 256) * (co // 128) >= 384) else 64      # narrow tiles on small grids
-            kern = "conv3x3_halo_kernel<128," if hb == 128 else "conv3x3_halo_rw_kernel<"      # 64 wide: patch-row window
             if Wo % 32 == 0 and Ho % 8 == 0:
-                return kern + "8,32>"
+                return "conv3x3_halo_rw_kernel<8,32>"
             if Wo % 16 == 0 and Ho % 16 == 0:
-                return kern + "16,16>"
+                return "conv3x3_halo_rw_kernel<16,16>"
         k64 = ci % 64 == 0
         if bn == 128:
             return "conv_igemm_dma_kernel<128,64,2>" if k64 else "conv_igemm_dma_kernel<128,32,3>"

@@ -131,6 +131,48 @@ class AdamW(torch.optim.Optimizer):
                             float(gr["eps"]), float(gr["weight_decay"]), coef, float(self.inv_scale), amp_inv, finf, st["step"])
         return None
 
+    # ---- checkpoints in torch.optim.AdamW's own format (the reference saves only model weights, helpers.py:394-400;
+    # SURVEY.md 8f N3 asks for resumable optimiser state) ------------------------------------------------------------
+    def state_dict(self):
+        """Same structure as torch.optim.AdamW.state_dict(): per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq``
+        (views of the flat moment buffers are copied out), so either optimiser can load the other's checkpoint."""
+        state, groups, idx = {}, [], 0
+        for gr, st in zip(self.param_groups, self._st):
+            step = float(st["step"].item())
+            ids = []
+            for p in gr["params"]:
+                off = (p.data_ptr() - st["p"].data_ptr()) // 4 - st["lo"]
+                state[idx] = {"step": torch.tensor(step), "exp_avg": st["m"][off:off + p.numel()].view(p.shape).clone(),
+                              "exp_avg_sq": st["v"][off:off + p.numel()].view(p.shape).clone()}
+                ids.append(idx)
+                idx += 1
+            groups.append({**{k: v for k, v in gr.items() if k != "params"}, "params": ids})
+        return {"state": state, "param_groups": groups}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd):
+        groups = sd["param_groups"]
+        if len(groups) != len(self.param_groups) or any(len(g["params"]) != len(s["params"]) for g, s in zip(groups, self.param_groups)):
+            raise ValueError("loaded state dict has a different parameter-group layout")
+        for gr, st, g_in in zip(self.param_groups, self._st, groups):
+            for k, v in g_in.items():
+                if k != "params":
+                    gr[k] = v
+            steps = set()
+            for p, i in zip(gr["params"], g_in["params"]):
+                ps = sd["state"].get(i)
+                if ps is None:
+                    continue
+                off = (p.data_ptr() - st["p"].data_ptr()) // 4 - st["lo"]
+                st["m"][off:off + p.numel()].copy_(ps["exp_avg"].reshape(-1))
+                st["v"][off:off + p.numel()].copy_(ps["exp_avg_sq"].reshape(-1))
+                steps.add(int(float(ps["step"])))
+            if len(steps) > 1:
+                raise ValueError("mi355.optim.AdamW keeps one step counter per parameter group; the checkpoint has several")
+            if steps:
+                st["step"].fill_(steps.pop())
+            st["lr_host"] = None                  # force the device-side lr to be refreshed from the loaded group
+
     def zero_grad(self, set_to_none: bool = True):
         # gradients are (re)written, not accumulated, by every backward plan: dropping the views is enough
         for gr in self.param_groups:

@@ -358,3 +358,64 @@ def test_seg_counts():
     exp = torch.stack([(pb & tb).flatten(1).sum(1), pb.flatten(1).sum(1), tb.flatten(1).sum(1),
                        (pb == tb).flatten(1).sum(1)], 1).float()
     assert torch.equal(cnt.cpu(), exp)
+
+
+def test_adamw_checkpoint_interoperates_with_torch():
+    import copy
+    """mi355.optim.AdamW.state_dict() has torch.optim.AdamW's layout: a torch optimiser continues from our checkpoint
+    and we continue from torch's, bit-compatibly with an uninterrupted run (resume, SURVEY.md 8f N3)."""
+    from mi355 import optim as moptim
+    from models.classification_models.ResNet import ResNet18
+    torch.manual_seed(0)
+    m = ResNet18(num_classes=3)
+    m.compute_dtype = torch.float32
+    m = m.to(DEV).train()
+    m.engine._check_storage()
+    ps = list(m.parameters())
+    g = torch.Generator().manual_seed(3)
+    grads = [[torch.randn(p.shape, generator=g) * 0.01 for p in ps] for _ in range(4)]
+
+    def run(opt, k0, k1, params):
+        for k in range(k0, k1):
+            for p, gr in zip(params, grads[k]):
+                p.grad = gr.to(p.device)
+            if isinstance(opt, moptim.AdamW):
+                m.engine.flat_g.zero_()
+                for p, gr in zip(params, grads[k]):
+                    m.engine.grad_view(p).copy_(gr.to(DEV))
+            opt.step()
+
+    p0 = [p.detach().clone() for p in ps]
+    ours = moptim.AdamW(ps, lr=1e-3, weight_decay=5e-4)
+    run(ours, 0, 2, ps)
+    sd = ours.state_dict()
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 2.0
+    # torch continues from our checkpoint
+    tp = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    topt = torch.optim.AdamW(tp, lr=1e-3, weight_decay=5e-4)
+    topt.load_state_dict(copy.deepcopy(sd))        # (torch keeps the `step` tensors by reference and bumps them in place)
+    run(topt, 2, 4, tp)
+    # we continue from our own checkpoint in a fresh optimiser
+    fresh = moptim.AdamW(ps, lr=1e-3, weight_decay=5e-4)
+    fresh.load_state_dict(sd)
+    run(fresh, 2, 4, ps)
+    torch.cuda.synchronize()
+    for a, b in zip(ps, tp):
+        assert rel_err(a.detach().cpu(), b.detach().cpu()) < 1e-5
+    # and from torch's checkpoint: restart both from the initial weights
+    with torch.no_grad():
+        for p, q0 in zip(ps, p0):
+            p.copy_(q0)
+    tp2 = [torch.nn.Parameter(q0.clone()) for q0 in p0]
+    t2 = torch.optim.AdamW(tp2, lr=1e-3, weight_decay=5e-4)
+    run(t2, 0, 2, tp2)
+    with torch.no_grad():
+        for p, q in zip(ps, tp2):
+            p.copy_(q)
+    back = moptim.AdamW(ps, lr=1e-3, weight_decay=5e-4)
+    back.load_state_dict(copy.deepcopy(t2.state_dict()))
+    run(back, 2, 4, ps)
+    run(t2, 2, 4, tp2)
+    torch.cuda.synchronize()
+    for a, b in zip(ps, tp2):
+        assert rel_err(a.detach().cpu(), b.detach().cpu()) < 1e-5

@@ -72,8 +72,9 @@ int mi355_pack_conv_weights_batched(const int64_t* table, int n, int dtype, mi35
  * ConvTranspose2d(k,s)        : data-gradient form with wk = Wf of the transposed parameter
  *   (ResnetUnet.py:21,51).
  * Ci % 32 == 0 (16 for fp32), Co % 32 == 0.  accumulate != 0 adds into `out`.
- * bf16 dispatch: 3x3/s1 on tile-divisible images -> conv3x3_halo_kernel (halo patch in LDS, LDS-DMA),
- * everything else -> conv_igemm_dma_kernel (LDS-DMA ring); fp32 -> register-staged conv_igemm_kernel. */
+ * bf16 / fp16 dispatch: 3x3/s1/p1 with Co % 64 == 0 on images divisible by an 8x32 or 16x16 tile ->
+ * conv3x3_halo_rw_kernel (halo patch in LDS by LDS-DMA, patch-row register window), everything else ->
+ * conv_igemm_dma_kernel (LDS-DMA ring); fp32 -> register-staged conv_igemm_kernel. */
 int mi355_conv2d_igemm(const void* in, const void* wk, const float* bias, void* out,
                        int N, int Hi, int Wi, int Ci, int ldi,
                        int Ho, int Wo, int Co, int ldo,

@@ -57,9 +57,11 @@ int mi355_pack_nchw(const float* x, void* y, int N, int C, int H, int W, int ld,
 int mi355_pack_conv_weight(const float* w, void* wf, void* wb, int Co, int Ci, int Cip, int KH, int KW,
                            int transposed, int dtype, mi355_stream_t s);
 
-/* Every weight pack of a launch plan in ONE launch: `table` = n descriptors of 8 int64 in device memory
- * {w, wf, wb (0 = none), Co, Ci, Cip, KH*KW, transposed}, same semantics as mi355_pack_conv_weight. */
-int mi355_pack_conv_weights_batched(const int64_t* table, int n, int dtype, mi355_stream_t s);
+/* Every weight pack of a launch plan in ONE launch: `table` = n descriptors of 9 int64 in device memory
+ * {w, wf, wb (0 = none), Co, Ci, Cip, KH*KW, transposed, scale (0 = none)}, same semantics as mi355_pack_conv_weight;
+ * scale[Co] multiplies the rows of the packs (eval-mode BatchNorm folded into the weights, !transposed only). */
+int mi355_pack_conv_weights_batched(const int64_t* table, int n, int fields /* = 9: checked, the table is device memory */,
+                                    int dtype, mi355_stream_t s);
 
 /* ---- implicit-GEMM convolution on MFMA -------------------------------------------------
  * out[m][j] (+)= bias[j] + sum_{kh,kw,c} in[src(m,kh,kw)][c] * wk[j][kh*KW+kw][c]
@@ -71,7 +73,9 @@ int mi355_pack_conv_weights_batched(const int64_t* table, int n, int dtype, mi35
  *   input grad, reached from loss.backward(), utils/helpers.py:329)
  * ConvTranspose2d(k,s)        : data-gradient form with wk = Wf of the transposed parameter
  *   (ResnetUnet.py:21,51).
- * Ci % 32 == 0 (16 for fp32), Co % 32 == 0.  accumulate != 0 adds into `out`.
+ * Ci % 32 == 0 (16 for fp32), Co % 32 == 0.  `accumulate` is a bit set: bit 0 adds the result into `out`,
+ * bit 1 applies max(0, .) to conv + bias first (nn.ReLU fused into the epilogue: VGG.py:9-41, and eval-mode
+ * Conv -> BN -> ReLU with the BN folded into weights and bias).
  * bf16 / fp16 dispatch: 3x3/s1/p1 with Co % 64 == 0 on images divisible by an 8x32 or 16x16 tile ->
  * conv3x3_halo_rw_kernel (halo patch in LDS by LDS-DMA, patch-row register window), everything else ->
  * conv_igemm_dma_kernel (LDS-DMA ring); fp32 -> register-staged conv_igemm_kernel. */
@@ -113,6 +117,8 @@ int mi355_bn_finalize(const float* partial, int nblocks, long long M, int C, con
                       float momentum, float eps, float* scale, float* shift, float* mean, float* invstd,
                       mi355_stream_t s);
 /* Eval-mode scale/shift from running stats. */
+/* out[c] = scale[c] * (bias ? bias[c] : 0) + shift[c]: the bias of a convolution with eval-mode BN folded in. */
+int mi355_bn_fold_bias(const float* bias, const float* scale, const float* shift, float* out, int C, mi355_stream_t s);
 int mi355_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float eps, int C, float* scale, float* shift,
                          mi355_stream_t s);

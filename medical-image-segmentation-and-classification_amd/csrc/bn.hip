@@ -122,6 +122,19 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
   shift[c] = beta[c] - rm[c] * sc;
 }
 
+// eval-mode folding: conv(x; w*scale) + (scale*bias + shift) == bn(conv(x; w) + bias)
+__global__ void bn_fold_bias_kernel(const float* bias, const float* scale, const float* shift, float* out, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) out[c] = scale[c] * (bias ? bias[c] : 0.f) + shift[c];
+}
+
+extern "C" int mi355_bn_fold_bias(const float* bias, const float* scale, const float* shift, float* out, int C, mi355_stream_t s) {
+  MI355_CHECK_ARG(scale && shift && out && C > 0, "bn_fold_bias: bad arguments");
+  hipLaunchKernelGGL(bn_fold_bias_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, (hipStream_t)s, bias, scale, shift, out, C);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
 extern "C" int mi355_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                                     const float* running_var, float eps, int C, float* scale, float* shift,
                                     mi355_stream_t s) {

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_rw_kernel(const ConvArgs 
       for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float v = to_f32<T>(from_f32<T>(acc[mb][nb][r] + bcol[nb]));
+          const float v = to_f32<T>(from_f32<T>(a.relu ? fmaxf(acc[mb][nb][r] + bcol[nb], 0.f) : acc[mb][nb][r] + bcol[nb]));
           sm += v;
           sq += v * v;
         }
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_rw_kernel(const ConvArgs 
       for (int r = 0; r < 4; ++r) {
         const int row = wm * WTM + mb * 16 + c4 * 4 + r;
         const int col = wn * WTN + nb * 16 + l16;
-        *reinterpret_cast<T*>(lds + row * C_PITCH + col * 2) = from_f32<T>(acc[mb][nb][r] + bcol[nb]);
+        *reinterpret_cast<T*>(lds + row * C_PITCH + col * 2) = from_f32<T>(a.relu ? fmaxf(acc[mb][nb][r] + bcol[nb], 0.f) : acc[mb][nb][r] + bcol[nb]);
       }
   __syncthreads();
   if (a.stats && tid < 2 * BN) {

@@ -23,6 +23,7 @@ struct ConvArgs {
   int KH, KW;
   int mul, kmul, off, dshift, up;
   int accumulate;
+  int relu;        // epilogue: max(0, conv + bias) before rounding / accumulation (bit 1 of the ABI's `accumulate`)
   float* stats;  // optional fused BatchNorm statistics: partial[(mblock*2+q)*Co + c], q = sum / sum of squares
   int M;        // N*Ho*Wo
   int HoWo;
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
           if (m < a.M) {
             T* p = out + (size_t)m * a.ldo + n0 + wn * WTN + ni * 32 + r32;
             float v = acc[mi][ni][r] + bcol[ni];
+            if (a.relu) v = fmaxf(v, 0.f);
             if (a.accumulate) v += to_f32<T>(*p);
             *p = from_f32<T>(v);
           }
@@ -238,7 +240,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         for (int r = 0; r < 16; ++r) {
           const int row = wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
           const int col = wn * WTN + ni * 32 + r32;
-          *reinterpret_cast<T*>(lds + row * C_PITCH + col * (int)sizeof(T)) = from_f32<T>(acc[mi][ni][r] + bcol[ni]);
+          *reinterpret_cast<T*>(lds + row * C_PITCH + col * (int)sizeof(T)) =
+              from_f32<T>(a.relu ? fmaxf(acc[mi][ni][r] + bcol[ni], 0.f) : acc[mi][ni][r] + bcol[ni]);
         }
     __syncthreads();
     constexpr int CPRC = BN / EPC;
@@ -445,7 +448,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const float v = (m0 + row < a.M) ? to_f32<T>(from_f32<T>(acc[mi][ni][r] + bcol[ni])) : 0.f;
+          const float v = (m0 + row < a.M) ? to_f32<T>(from_f32<T>(a.relu ? fmaxf(acc[mi][ni][r] + bcol[ni], 0.f) : acc[mi][ni][r] + bcol[ni])) : 0.f;
           sm += v;
           sq += v * v;
         }
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvArgs a) {
       for (int r = 0; r < 16; ++r) {
         const int row = wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const int col = wn * WTN + ni * 32 + r32;
-        *reinterpret_cast<T*>(lds + row * C_PITCH + col * 2) = from_f32<T>(acc[mi][ni][r] + bcol[ni]);
+        *reinterpret_cast<T*>(lds + row * C_PITCH + col * 2) = from_f32<T>(a.relu ? fmaxf(acc[mi][ni][r] + bcol[ni], 0.f) : acc[mi][ni][r] + bcol[ni]);
       }
   __syncthreads();
   if (a.stats && tid < 2 * BN) {
@@ -564,7 +567,7 @@ extern "C" int mi355_conv2d_igemm(const void* in, const void* wk, const float* b
                   "conv2d_igemm: pointers / channel strides must be 16-byte aligned");
   MI355_CHECK_ARG(Ci % (esz == 2 ? 32 : 16) == 0, "conv2d_igemm: Ci=%d must be a multiple of %d", Ci, esz == 2 ? 32 : 16);
   const IgemmVariant v = pick_variant(Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up, dtype);
-  MI355_CHECK_ARG(!stats || (v != IG_GENERIC && !accumulate),
+  MI355_CHECK_ARG(!stats || (v != IG_GENERIC && !(accumulate & 1)),
                   "conv2d_igemm: fused statistics are not available for this shape/dtype (mi355_conv2d_igemm_stat_rows == 0)");
   ConvArgs a;
   a.in = in; a.wk = wk; a.bias = bias; a.out = out;
@@ -573,7 +576,8 @@ extern "C" int mi355_conv2d_igemm(const void* in, const void* wk, const float* b
   a.KH = KH; a.KW = KW; a.mul = mul; a.kmul = kmul; a.off = off;
   a.dshift = div == 1 ? 0 : (div == 2 ? 1 : 2);
   a.up = up ? 1 : 0;
-  a.accumulate = accumulate;
+  a.accumulate = accumulate & 1;
+  a.relu = (accumulate >> 1) & 1;
   a.stats = stats;
   a.M = N * Ho * Wo;
   a.HoWo = Ho * Wo;

@@ -119,7 +119,8 @@ extern "C" int mi355_pack_conv_weight(const float* w, void* wf, void* wb, int Co
 }
 
 // All weight packs of a plan in ONE launch: blockIdx.y selects the descriptor
-// {w, wf, wb, Co, Ci, Cip, taps, transposed} (8 x int64 each, device memory); blockIdx.x strides 32 x TB tiles of
+// {w, wf, wb, Co, Ci, Cip, taps, transposed, scale} (9 x int64 each, device memory; scale: optional per-output-channel
+// factor folded into the packs — eval-mode BatchNorm); blockIdx.x strides 32 x TB tiles of
 // the parameter's two outer dimensions (w[a][b][tap]: a = co, b = ci; ConvTranspose: a = ci, b = co).  A tile is
 // read with coalesced rows (TB*taps contiguous floats per a), parked in LDS, and written twice: once with b as
 // the inner dimension, once with a — both as contiguous 32-element runs.
@@ -127,11 +128,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void pack_weight_batched_kernel(const long long* __restrict__ table) {
   constexpr int TA = 32, ROWMAX = 288, PITCH = ROWMAX + 1;
   __shared__ float tile[TA * PITCH];
-  const long long* d = table + (size_t)blockIdx.y * 8;
+  const long long* d = table + (size_t)blockIdx.y * 9;
   const float* __restrict__ w = reinterpret_cast<const float*>(d[0]);
   T* __restrict__ wf = reinterpret_cast<T*>(d[1]);
   T* __restrict__ wb = reinterpret_cast<T*>(d[2]);
   const int Co = (int)d[3], Ci = (int)d[4], Cip = (int)d[5], taps = (int)d[6], transposed = (int)d[7];
+  const float* __restrict__ oscale = reinterpret_cast<const float*>(d[8]);      // per output channel (a when !transposed)
   const int A = transposed ? Ci : Co, B = transposed ? Co : Ci;          // extents present in w
   const int Ap = transposed ? Cip : Co, Bp = transposed ? Co : Cip;      // extents of the packs (ci padded to Cip)
   int TB = ROWMAX / taps;
@@ -149,7 +151,8 @@ __global__ __launch_bounds__(256) void pack_weight_batched_kernel(const long lon
     for (int r = wave; r < na; r += 4) {
       const int a = a0 + r;
       const float* src = w + ((size_t)a * B + b0) * taps;
-      for (int e = lane; e < len; e += 64) tile[r * PITCH + e] = (a < A && e < nbv) ? src[e] : 0.f;
+      const float f = (oscale && !transposed && a < A) ? oscale[a] : 1.f;
+      for (int e = lane; e < len; e += 64) tile[r * PITCH + e] = (a < A && e < nbv) ? src[e] * f : 0.f;
     }
     __syncthreads();
     if (out_b) {
@@ -169,8 +172,9 @@ __global__ __launch_bounds__(256) void pack_weight_batched_kernel(const long lon
   }
 }
 
-extern "C" int mi355_pack_conv_weights_batched(const int64_t* table, int n, int dtype, mi355_stream_t s) {
+extern "C" int mi355_pack_conv_weights_batched(const int64_t* table, int n, int fields, int dtype, mi355_stream_t s) {
   MI355_CHECK_ARG(table && n > 0 && n <= 65535, "pack_conv_weights_batched: bad arguments");
+  MI355_CHECK_ARG(fields == 9, "pack_conv_weights_batched: descriptors have 9 int64 fields, the caller built %d", fields);
   dim3 grid(256, n);     // 256 workgroups stride the tiles of each descriptor (largest: 1024 x 512 x 9 = 512 tiles)
   return dispatch_dtype(dtype, "pack_weight_batched_kernel", [&](auto tag) {
     using T = decltype(tag);

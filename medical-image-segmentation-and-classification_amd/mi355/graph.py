@@ -374,8 +374,9 @@ class Builder:
         return out
 
     # ---- packed weights -------------------------------------------------------------------------------
-    def packs(self, conv, cip, transposed=False):
-        key = (id(conv), cip)
+    def packs(self, conv, cip, transposed=False, scale=None):
+        """(Wf, Wb) packs of a conv parameter; ``scale`` (per output channel, device fp32) is folded into them."""
+        key = (id(conv), cip, id(scale))
         if key not in self._packs:
             w = conv.weight
             if transposed:
@@ -386,7 +387,7 @@ class Builder:
             wf = self._alloc(co * k * k * cip)
             wb = self._alloc(co * k * k * cip) if self.want_grad else None
             assert k * k <= 288, "batched weight pack: at most 288 taps"
-            self._pack_table.append((w, wf, wb, co, ci, cip, k * k, 1 if transposed else 0))
+            self._pack_table.append((w, wf, wb, co, ci, cip, k * k, 1 if transposed else 0, scale))
             self.see(w, conv.bias)
             self._packs[key] = (wf, wb)
         return self._packs[key]
@@ -399,14 +400,16 @@ class Builder:
         hl, wl = (2 * x.H, 2 * x.W) if up else (x.H, x.W)
         return k, s, p, (hl + 2 * p - k) // s + 1, (wl + 2 * p - k) // s + 1
 
-    def conv_raw(self, x, conv, up=False, out=None, stats=False):
+    def conv_raw(self, x, conv, up=False, out=None, stats=False, relu=False, fold=None):
         """y = conv(x) (+bias), raw output in the compute dtype; returns (y, bwd(dy, bias_done)).  With
         ``stats`` the BatchNorm partial sums of y are produced by the conv epilogue when the kernel supports
-        it (``self._last_stat_rows`` > 0 afterwards)."""
+        it (``self._last_stat_rows`` > 0 afterwards).  ``relu``: max(0, .) in the epilogue.  ``fold = (scale, bias)``:
+        eval-mode BatchNorm folded into the packed weights and the bias (forward-only plans)."""
         k, s, p, Ho, Wo = self._conv_geom(x, conv, up)
         Co = conv.out_channels
         assert x.C >= conv.in_channels and (x.C == conv.in_channels or conv.in_channels < CPAD), (x.C, conv.in_channels)
-        wf, wb = self.packs(conv, x.C)
+        wf, wb = self.packs(conv, x.C, scale=fold[0] if fold else None)
+        bias = fold[1] if fold else conv.bias
         y = out if out is not None else self.new_tensor(x.N, Ho, Wo, Co)
         assert (y.N, y.H, y.W, y.C) == (x.N, Ho, Wo, Co)
         flops = 2 * x.N * Ho * Wo * Co * k * k * conv.in_channels
@@ -419,8 +422,8 @@ class Builder:
             if rows > 0:            # the kernel serving this shape folds the BatchNorm statistics into its epilogue
                 stat_part = self.ws_f32(rows * 2 * Co)
                 self._last_stat_rows = rows
-        self.fwd.append(Launch("mi355_conv2d_igemm", x, wf, conv.bias, y, x.N, x.H, x.W, x.C, x.ld, Ho, Wo, Co, y.ld,
-                               k, k, s, 1, -p, 1, 1 if up else 0, 0, stat_part, self.code, flops=flops, nbytes=nbytes,
+        self.fwd.append(Launch("mi355_conv2d_igemm", x, wf, bias, y, x.N, x.H, x.W, x.C, x.ld, Ho, Wo, Co, y.ld,
+                               k, k, s, 1, -p, 1, 1 if up else 0, 2 if relu else 0, stat_part, self.code, flops=flops, nbytes=nbytes,
                                tag=self.igemm_tag(Co, x.C, k, s, Ho, Wo, False, up, M=x.N * Ho * Wo)))
         y.needs_grad = x.needs_grad or conv.weight.requires_grad
 
@@ -562,6 +565,17 @@ class Builder:
         """act(bn(conv(x)) [+ res]) [+ post_add] — the workhorse (AttentionUNet.py:4-13,15-27; ResNet.py:36-44;
         ``post_add``: the recurrent block's x + relu(bn(conv(.))) (R2AttU_Net.py:44) produced in one pass)."""
         assert res is None or post_add is None
+        if not self.training and not self.want_grad and res is None and post_add is None and bn.track_running_stats:
+            # inference: BN(running statistics) folded into the packed weights and the bias, ReLU in the conv epilogue —
+            # one launch, no normalisation pass (pipeline.py:324-357 runs the models in eval mode)
+            sc, sh, fb = self.f32(bn.num_features), self.f32(bn.num_features), self.f32(bn.num_features)
+            self.see(bn.weight, bn.bias)
+            self.pre.append(Launch("mi355_bn_eval_coeffs", bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps),
+                                   bn.num_features, sc, sh))
+            self.pre.append(Launch("mi355_bn_fold_bias", conv.bias, sc, sh, fb, bn.num_features))
+            a, _ = self.conv_raw(x, conv, up, out=out, relu=act, fold=(sc, fb))
+            a.needs_grad = False
+            return a
         y, conv_bwd = self.conv_raw(x, conv, up, stats=True)
         st = self._bn_coeffs(y, bn, self._last_stat_rows)
         a = out if out is not None else self.new_tensor(y.N, y.H, y.W, y.C)
@@ -605,16 +619,14 @@ class Builder:
 
     def conv_act(self, x, conv, relu=False, up=False, out=None):
         """conv (+bias) with optional ReLU and no normalisation (VGG.py:9-41; R2AttU_Net.py:54)."""
-        y, conv_bwd = self.conv_raw(x, conv, up, out=None if relu else out)
+        y, conv_bwd = self.conv_raw(x, conv, up, out=out, relu=relu)        # ReLU rides in the conv epilogue
         if not relu:
             def rule():
                 if y.needs_grad:
                     conv_bwd(self.grad_of(y))
             self.rule(rule)
             return y
-        a = out if out is not None else self.new_tensor(y.N, y.H, y.W, y.C)
-        self.fwd.append(Launch("mi355_relu_fwd", y, y.ld, a, a.ld, y.M, y.C, self.code))
-        a.needs_grad = y.needs_grad
+        a = y                                                                 # (relu'(.) is recovered from a > 0)
 
         def rule():
             if not a.needs_grad:
@@ -974,11 +986,11 @@ class Builder:
     # ---- finish -------------------------------------------------------------------------------------------------------------
     def finish(self):
         if self._pack_table:
-            rows = [[w.data_ptr(), wf.data_ptr(), wb.data_ptr() if wb is not None else 0, co, ci, cip, taps, tr]
-                    for (w, wf, wb, co, ci, cip, taps, tr) in self._pack_table]
+            rows = [[w.data_ptr(), wf.data_ptr(), wb.data_ptr() if wb is not None else 0, co, ci, cip, taps, tr,
+                     sc.data_ptr() if sc is not None else 0] for (w, wf, wb, co, ci, cip, taps, tr, sc) in self._pack_table]
             table = torch.tensor(rows, dtype=torch.int64).to(self.device)
             self.keep.append(table)
-            self.pre.append(Launch("mi355_pack_conv_weights_batched", table, len(rows), self.code))
+            self.pre.append(Launch("mi355_pack_conv_weights_batched", table, len(rows), len(rows[0]), self.code))
         for r in reversed(self._rules):
             r()
         # resolve _WsOff into (tensor, byte offset) late-bound pairs

@@ -177,18 +177,25 @@ def test_pack_unpack_and_weight_pack(dtype):
     cases = [((40, 3, 3, 3), 32, 0, True), ((3, 40, 2, 2), 32, 1, True), ((64, 3, 7, 7), 32, 0, False),
              ((96, 160, 3, 3), 160, 0, True), ((37, 64, 1, 1), 64, 0, True), ((64, 32, 2, 2), 64, 1, True)]
     rows, outs = [], []
-    for shape, cip, tr, has_wb in cases:
+    for i, (shape, cip, tr, has_wb) in enumerate(cases):
         w = torch.randn(*shape, generator=g)
         co, ci = (shape[1], shape[0]) if tr else (shape[0], shape[1])
         wf_ref, wb_ref = pack_w(w, dtype, cip=cip, transposed=bool(tr))
         wd = dev(w)
         wf = torch.full_like(wf_ref, float("nan")); wb = torch.full_like(wb_ref, float("nan")) if has_wb else None
-        rows.append([wd.data_ptr(), wf.data_ptr(), wb.data_ptr() if has_wb else 0, co, ci, cip, shape[2] * shape[3], tr])
-        outs.append((wd, wf, wb, wf_ref, wb_ref))
+        sc = (torch.rand(co, generator=g) + 0.5) if (i % 2 == 0 and not tr) else None      # folded per-output-channel scale
+        if sc is not None:
+            wf_ref, wb_ref = pack_w(w * sc.view(-1, 1, 1, 1), dtype, cip=cip)
+        scd = dev(sc) if sc is not None else None
+        rows.append([wd.data_ptr(), wf.data_ptr(), wb.data_ptr() if has_wb else 0, co, ci, cip, shape[2] * shape[3], tr,
+                     scd.data_ptr() if scd is not None else 0])
+        outs.append((wd, wf, wb, wf_ref, wb_ref, scd))
     table = torch.tensor(rows, dtype=torch.int64).to(DEV)
-    lib.mi355_pack_conv_weights_batched(table, len(rows), code)
+    with pytest.raises(RuntimeError):
+        lib.mi355_pack_conv_weights_batched(table, len(rows), 8, code)        # a stale descriptor layout is refused on the host
+    lib.mi355_pack_conv_weights_batched(table, len(rows), 9, code)
     torch.cuda.synchronize()
-    for i, (wd, wf, wb, wf_ref, wb_ref) in enumerate(outs):
+    for i, (wd, wf, wb, wf_ref, wb_ref, _) in enumerate(outs):
         assert torch.equal(wf, wf_ref), cases[i]
         assert wb is None or torch.equal(wb, wb_ref), cases[i]
 

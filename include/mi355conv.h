@@ -199,7 +199,10 @@ int mi355_global_pool_bwd(const float* dy, const int32_t* argmax, void* dx, int 
 int mi355_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int I, int O, int relu,
                      mi355_stream_t s);
 int mi355_linear_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw,
-                     float* db, int B, int I, int O, int relu, float beta, mi355_stream_t s);
+                     float* db, int B, int I, int O, int relu, float beta, float* scratch, mi355_stream_t s);
+/* fp32 elements of `scratch` mi355_linear_bwd needs to produce dx (0 for small layers; the wide layers of the torchvision
+ * VGG head — 25088 x 4096 — stream W once per 16 batch rows and fold 16 deterministic output-range partials). */
+int mi355_linear_bwd_scratch(int B, int I, int O);
 /* inverted dropout with a counter hash (seed, counter[0], element index): mask byte kept for backward;
  * `counter` is a device word the host bumps per forward so a static launch plan draws fresh masks. */
 int mi355_dropout_fwd(const float* x, float* y, uint8_t* mask, long long n, float p, uint64_t seed,

@@ -98,13 +98,138 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
   }
 }
 
+// ---- wide Linear layers (torchvision VGG head: 25088 -> 4096 -> 4096) ------------------------------------------------
+// M = batch is tiny, so these are streaming passes over the weight matrix: every kernel below touches W (or dW)
+// exactly once per 16 batch rows with 16-byte accesses, keeps the batch-side operand in registers and never uses
+// atomics.  Algorithmic bytes: forward O*I*4 read; backward O*I*4 read (dx) + O*I*4 written (dW).
+constexpr int LIN_BT = 16;      // batch rows per pass
+
+// y[b][o] = act(sum_i x[b][i] w[o][i] + bias[o]): one wave per output row o, lanes stride the row in float4s
+__global__ __launch_bounds__(256) void linear_fwd_wide_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ y, int B, int I,
+                                                              int O, int relu) {
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int b0 = blockIdx.y * LIN_BT, nb = min(LIN_BT, B - b0);
+  if (o >= O) return;
+  float acc[LIN_BT];
+#pragma unroll
+  for (int b = 0; b < LIN_BT; ++b) acc[b] = 0.f;
+  const float4* wr = reinterpret_cast<const float4*>(w + (size_t)o * I);
+  const int I4 = I >> 2;
+  for (int i = lane; i < I4; i += 64) {
+    const float4 wv = wr[i];
+#pragma unroll
+    for (int b = 0; b < LIN_BT; ++b) {
+      if (b < nb) {
+        const float4 xv = reinterpret_cast<const float4*>(x + (size_t)(b0 + b) * I)[i];
+        acc[b] += wv.x * xv.x + wv.y * xv.y + wv.z * xv.z + wv.w * xv.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < LIN_BT; ++b) {
+    const float v = wave_sum(acc[b]);
+    if (lane == 0 && b < nb) {
+      const float r = v + (bias ? bias[o] : 0.f);
+      y[(size_t)(b0 + b) * O + o] = relu ? fmaxf(r, 0.f) : r;
+    }
+  }
+}
+
+// partial dx: part[split][b][i] = sum_{o in split} g[b][o] w[o][i]; a thread owns four consecutive i
+__global__ __launch_bounds__(256) void linear_dx_wide_kernel(const float* __restrict__ w, const float* __restrict__ y,
+                                                             const float* __restrict__ dy, float* __restrict__ part, int B, int I,
+                                                             int O, int relu, int o_per_split) {
+  const int i4 = blockIdx.x * 256 + threadIdx.x;
+  const int b0 = blockIdx.z * LIN_BT, nb = min(LIN_BT, B - b0);
+  const int o0 = blockIdx.y * o_per_split, o1 = min(O, o0 + o_per_split);
+  if (i4 * 4 >= I) return;
+  float4 acc[LIN_BT];
+#pragma unroll
+  for (int b = 0; b < LIN_BT; ++b) acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int o = o0; o < o1; ++o) {
+    const float4 wv = reinterpret_cast<const float4*>(w + (size_t)o * I)[i4];
+#pragma unroll
+    for (int b = 0; b < LIN_BT; ++b) {
+      if (b < nb) {
+        float g = dy[(size_t)(b0 + b) * O + o];
+        if (relu && !(y[(size_t)(b0 + b) * O + o] > 0.f)) g = 0.f;
+        acc[b].x += g * wv.x; acc[b].y += g * wv.y; acc[b].z += g * wv.z; acc[b].w += g * wv.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < LIN_BT; ++b)
+    if (b < nb) reinterpret_cast<float4*>(part + ((size_t)blockIdx.y * B + b0 + b) * I)[i4] = acc[b];
+}
+
+__global__ void linear_dx_fold_kernel(const float* __restrict__ part, float* __restrict__ dx, int splits, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += part[(size_t)k * n + i];
+    dx[i] = s;
+  }
+}
+
+// dW[o][i] = beta*dW + sum_b g[b][o] x[b][i] (+ db): a thread keeps x[:, i..i+3] in registers and walks 64 output rows
+__global__ __launch_bounds__(256) void linear_dw_wide_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                             const float* __restrict__ dy, float* __restrict__ dw,
+                                                             float* __restrict__ db, int B, int I, int O, int relu, float beta) {
+  const int i4 = blockIdx.x * 256 + threadIdx.x;
+  const int o0 = blockIdx.y * 64, o1 = min(O, o0 + 64);
+  const bool live = i4 * 4 < I;
+  for (int b0 = 0; b0 < B; b0 += LIN_BT) {                     // (B <= 16 in every configuration: one trip)
+    const int nb = min(LIN_BT, B - b0);
+    float4 xv[LIN_BT];
+#pragma unroll
+    for (int b = 0; b < LIN_BT; ++b)
+      xv[b] = (live && b < nb) ? reinterpret_cast<const float4*>(x + (size_t)(b0 + b) * I)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int o = o0; o < o1; ++o) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      float sb = 0.f;
+#pragma unroll
+      for (int b = 0; b < LIN_BT; ++b) {
+        if (b < nb) {
+          float g = dy[(size_t)(b0 + b) * O + o];
+          if (relu && !(y[(size_t)(b0 + b) * O + o] > 0.f)) g = 0.f;
+          acc.x += g * xv[b].x; acc.y += g * xv[b].y; acc.z += g * xv[b].z; acc.w += g * xv[b].w;
+          sb += g;
+        }
+      }
+      const float keep = (b0 == 0) ? beta : 1.f;                // later batch chunks accumulate onto the first
+      if (live) {
+        float4* p = reinterpret_cast<float4*>(dw + (size_t)o * I) + i4;
+        if (keep != 0.f) {
+          const float4 old = *p;
+          acc.x += keep * old.x; acc.y += keep * old.y; acc.z += keep * old.z; acc.w += keep * old.w;
+        }
+        *p = acc;
+      }
+      if (db && blockIdx.x == 0 && threadIdx.x == 0) db[o] = (keep != 0.f ? keep * db[o] : 0.f) + sb;
+    }
+  }
+}
+
+static inline bool linear_wide(int B, int I, int O) { return I % 4 == 0 && (long long)I * O >= (1 << 20) && B >= 1; }
+
 extern "C" int mi355_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int I, int O, int relu,
                                 mi355_stream_t s) {
   MI355_CHECK_ARG(x && w && y, "linear_fwd: null pointer");
-  hipLaunchKernelGGL(linear_fwd_kernel, dim3(ceil_div((long long)B * O, 4)), dim3(256), 0, (hipStream_t)s, x, w, bias, y, B, I, O,
-                     relu);
+  if (linear_wide(B, I, O))
+    hipLaunchKernelGGL(linear_fwd_wide_kernel, dim3(ceil_div(O, 4), ceil_div(B, LIN_BT)), dim3(256), 0, (hipStream_t)s, x, w, bias, y, B,
+                       I, O, relu);
+  else
+    hipLaunchKernelGGL(linear_fwd_kernel, dim3(ceil_div((long long)B * O, 4)), dim3(256), 0, (hipStream_t)s, x, w, bias, y, B, I, O,
+                       relu);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
+}
+
+/* scratch floats mi355_linear_bwd needs for the input gradient of a wide layer (0: none) */
+extern "C" int mi355_linear_bwd_scratch(int B, int I, int O) {
+  if (!linear_wide(B, I, O)) return 0;
+  const long long n = (long long)16 * B * I;
+  return n > 0x7fffffff ? -1 : (int)n;
 }
 
 // g = dy * (relu ? y > 0 : 1);  dx[b][i] = sum_o g[b][o] w[o][i];  dw[o][i] = beta*dw + sum_b g[b][o] x[b][i]
@@ -140,8 +265,23 @@ __global__ void linear_bwd_dw_kernel(const float* __restrict__ x, const float* _
 }
 
 extern "C" int mi355_linear_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw,
-                                float* db, int B, int I, int O, int relu, float beta, mi355_stream_t s) {
+                                float* db, int B, int I, int O, int relu, float beta, float* scratch, mi355_stream_t s) {
   MI355_CHECK_ARG(x && w && dy && (!relu || y), "linear_bwd: null pointer");
+  if (linear_wide(B, I, O)) {
+    if (dx) {
+      MI355_CHECK_ARG(scratch, "linear_bwd: a wide layer needs mi355_linear_bwd_scratch(B, I, O) floats of scratch for dx");
+      const int splits = 16, ops = ceil_div(O, splits);
+      hipLaunchKernelGGL(linear_dx_wide_kernel, dim3(ceil_div(I / 4, 256), splits, ceil_div(B, LIN_BT)), dim3(256), 0, (hipStream_t)s, w,
+                         y, dy, scratch, B, I, O, relu, ops);
+      hipLaunchKernelGGL(linear_dx_fold_kernel, dim3(ceil_div((long long)B * I, 256) > 2048 ? 2048 : ceil_div((long long)B * I, 256)),
+                         dim3(256), 0, (hipStream_t)s, scratch, dx, splits, (long long)B * I);
+    }
+    if (dw)
+      hipLaunchKernelGGL(linear_dw_wide_kernel, dim3(ceil_div(I / 4, 256), ceil_div(O, 64)), dim3(256), 0, (hipStream_t)s, x, y, dy, dw,
+                         db, B, I, O, relu, beta);
+    MI355_LAUNCH_CHECK();
+    return MI355_OK;
+  }
   if (dx) hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(ceil_div((long long)B * I, 256)), dim3(256), 0, (hipStream_t)s, w, y, dy, dx, B, I, O, relu);
   if (dw) hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(ceil_div((long long)O * I, 256)), dim3(256), 0, (hipStream_t)s, x, y, dy, dw, db, B, I, O, relu, beta);
   MI355_LAUNCH_CHECK();

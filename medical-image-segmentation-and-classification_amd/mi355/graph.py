@@ -895,7 +895,10 @@ class Builder:
                 dw, beta = self.pgrad(lin.weight)
                 if lin.bias is not None:
                     db, _ = self.pgrad(lin.bias)
-            self.bwd.append(Launch("mi355_linear_bwd", v, lin.weight, y, dy, dx, dw, db, v.B, v.F, O, 1 if relu else 0, beta))
+            need = lib.mi355_linear_bwd_scratch(v.B, v.F, O) if dx is not None else 0
+            assert need >= 0, "linear layer too large for the int32 scratch query"
+            scratch = self.ws_f32(need) if need else None
+            self.bwd.append(Launch("mi355_linear_bwd", v, lin.weight, y, dy, dx, dw, db, v.B, v.F, O, 1 if relu else 0, beta, scratch))
         self.rule(rule)
         return y
 

@@ -274,10 +274,31 @@ def test_heads_and_losses():
     yd = torch.empty(b, o, device=DEV)
     lib.mi355_linear_fwd(dev(x.detach()), dev(w.detach()), dev(bias.detach()), yd, b, i, o, 1)
     dx, dw, db = torch.empty(b, i, device=DEV), torch.zeros(o, i, device=DEV), torch.zeros(o, device=DEV)
-    lib.mi355_linear_bwd(dev(x.detach()), dev(w.detach()), yd, dev(dy), dx, dw, db, b, i, o, 1, 0.0)
+    assert lib.mi355_linear_bwd_scratch(b, i, o) == 0
+    lib.mi355_linear_bwd(dev(x.detach()), dev(w.detach()), yd, dev(dy), dx, dw, db, b, i, o, 1, 0.0, None)
     torch.cuda.synchronize()
     assert rel_err(yd.cpu(), y.detach()) < 1e-5 and rel_err(dx.cpu(), x.grad) < 1e-5
     assert rel_err(dw.cpu(), w.grad) < 1e-5 and rel_err(db.cpu(), bias.grad) < 1e-5
+    # wide layers (torchvision VGG head): streaming kernels; ragged batch (19 = 16 + 3), O not a multiple of the tiles,
+    # beta = 1 accumulation
+    for b, i, o, relu in ((19, 2052, 517, 1), (2, 4096, 300, 0)):
+        x = torch.randn(b, i, generator=g, requires_grad=True); w = (torch.randn(o, i, generator=g) / i ** 0.5).requires_grad_(True)
+        bias = torch.randn(o, generator=g, requires_grad=True)
+        lin = F.linear(x, w, bias)
+        y = F.relu(lin) if relu else lin
+        dy = torch.randn(b, o, generator=g); y.backward(dy)
+        yd = torch.empty(b, o, device=DEV)
+        lib.mi355_linear_fwd(dev(x.detach()), dev(w.detach()), dev(bias.detach()), yd, b, i, o, relu)
+        need = lib.mi355_linear_bwd_scratch(b, i, o)
+        assert need == 16 * b * i
+        scratch = torch.empty(need, device=DEV)
+        dx = torch.full((b, i), float("nan"), device=DEV); dw = torch.ones(o, i, device=DEV); db = torch.ones(o, device=DEV)
+        lib.mi355_linear_bwd(dev(x.detach()), dev(w.detach()), yd, dev(dy), dx, dw, db, b, i, o, relu, 1.0, scratch)
+        torch.cuda.synchronize()
+        assert rel_err(yd.cpu(), y.detach()) < 1e-5 and rel_err(dx.cpu(), x.grad) < 1e-5
+        assert rel_err(dw.cpu(), w.grad + 1) < 1e-5 and rel_err(db.cpu(), bias.grad + 1) < 1e-5
+        with pytest.raises(RuntimeError):
+            lib.mi355_linear_bwd(dev(x.detach()), dev(w.detach()), yd, dev(dy), dx, dw, db, b, i, o, relu, 0.0, None)
     # dropout: keep-rate and scaling
     nn_ = 1 << 18
     xx = torch.ones(nn_, device=DEV); yy = torch.empty(nn_, device=DEV); mk = torch.empty(nn_, dtype=torch.uint8, device=DEV)

@@ -249,6 +249,38 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_rw_kernel(const ConvArgs 
     a.stats[((size_t)(bid / NT) * 2 + q) * a.Co + n0 + c] = v;
   }
   constexpr int CPRC = BN / EPC;
+  if (a.pool2) {       // gradient of a fused nearest x2 up-sampling: the four outputs of a 2x2 group are summed (fp32, from the
+                       // ROUNDED tile values, as the separate mi355_upsample2_bwd pass did) into the half-resolution tensor
+    const int Ho2 = a.Ho >> 1, Wo2 = a.Wo >> 1;
+    for (int id = tid; id < (BM / 4) * CPRC; id += 256) {
+      const int g = id / CPRC, c = id - g * CPRC;
+      const int gy = g / (TW / 2), gx = g - gy * (TW / 2);
+      float sum[EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) sum[e] = 0.f;
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const int row = (2 * gy + dy) * TW + 2 * gx + dx;
+          const Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(lds + row * C_PITCH + c * 16);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) sum[e] += to_f32<T>(v.v[e]);
+        }
+      T* p = out + ((size_t)(n * Ho2 + (y0 >> 1) + gy) * Wo2 + (x0 >> 1) + gx) * a.ldo + n0 + c * EPC;
+      Vec16<T> v;
+      if (a.accumulate) {
+        const Vec16<T> o = ld16<T>(p);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v.v[e] = from_f32<T>(sum[e] + to_f32<T>(o.v[e]));
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v.v[e] = from_f32<T>(sum[e]);
+      }
+      st16<T>(p, v);
+    }
+    return;
+  }
   for (int id = tid; id < BM * CPRC; id += 256) {
     const int row = id / CPRC, c = id - row * CPRC;
     const int py = row / TW, px = row - py * TW;

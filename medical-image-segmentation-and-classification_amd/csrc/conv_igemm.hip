@@ -24,6 +24,7 @@ struct ConvArgs {
   int mul, kmul, off, dshift, up;
   int accumulate;
   int relu;        // epilogue: max(0, conv + bias) before rounding / accumulation (bit 1 of the ABI's `accumulate`)
+  int pool2;       // epilogue: sum 2x2 output-pixel groups, out is [N][Ho/2][Wo/2] (bit 2: gradient of a fused nearest x2 up-sampling)
   float* stats;  // optional fused BatchNorm statistics: partial[(mblock*2+q)*Co + c], q = sum / sum of squares
   int M;        // N*Ho*Wo
   int HoWo;
@@ -540,6 +541,11 @@ static IgemmVariant pick_variant(int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
   return IG_DMA;
 }
 
+extern "C" int mi355_conv2d_igemm_variant(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int mul, int kmul, int off,
+                                          int div, int up, int dtype) {
+  return (int)pick_variant(Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up, dtype);
+}
+
 extern "C" int mi355_conv2d_igemm_stat_rows(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int mul,
                                             int kmul, int off, int div, int up, int dtype) {
   switch (pick_variant(Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up, dtype)) {
@@ -578,6 +584,9 @@ extern "C" int mi355_conv2d_igemm(const void* in, const void* wk, const float* b
   a.up = up ? 1 : 0;
   a.accumulate = accumulate & 1;
   a.relu = (accumulate >> 1) & 1;
+  a.pool2 = (accumulate >> 2) & 1;
+  MI355_CHECK_ARG(!a.pool2 || ((v == IG_HALO_8x32 || v == IG_HALO_16x16) && !stats),
+                  "conv2d_igemm: the 2x2-sum epilogue exists for the halo kernel only (mi355_conv2d_igemm_variant >= 2)");
   a.stats = stats;
   a.M = N * Ho * Wo;
   a.HoWo = Ho * Wo;

@@ -440,13 +440,20 @@ class Builder:
                 self.bias_grad_from(dy, conv.bias)
             if x.needs_grad:
                 if up:
-                    tmp = self.new_tensor(x.N, 2 * x.H, 2 * x.W, x.C)
-                    self.bwd.append(Launch("mi355_conv2d_igemm", dy, wb, None, tmp, x.N, Ho, Wo, Co, dy.ld, 2 * x.H, 2 * x.W,
-                                           x.C, tmp.ld, k, k, 1, -1, p, s, 0, 0, None, self.code, flops=flops, nbytes=nbytes,
-                                           tag=self.igemm_tag(x.C, Co, k, s, 2 * x.H, 2 * x.W, True, False, M=x.N * 4 * x.H * x.W)))
                     acc = self.acc_flag(x)
                     xg = self.grad_of(x)
-                    self.bwd.append(Launch("mi355_upsample2_bwd", tmp, tmp.ld, xg, xg.ld, x.N, x.H, x.W, x.C, acc, self.code))
+                    tag = self.igemm_tag(x.C, Co, k, s, 2 * x.H, 2 * x.W, True, False, M=x.N * 4 * x.H * x.W)
+                    if lib.mi355_conv2d_igemm_variant(Ho, Wo, Co, 2 * x.H, 2 * x.W, x.C, k, k, 1, -1, p, s, 0, self.code) >= 2:
+                        # the data gradient lives on the up-sampled grid; its 2x2 sums go straight to the half-resolution
+                        # gradient in the kernel epilogue (no full-resolution temporary, no separate pass)
+                        self.bwd.append(Launch("mi355_conv2d_igemm", dy, wb, None, xg, x.N, Ho, Wo, Co, dy.ld, 2 * x.H, 2 * x.W,
+                                               x.C, xg.ld, k, k, 1, -1, p, s, 0, 4 | (1 if acc else 0), None, self.code, flops=flops,
+                                               nbytes=nbytes, tag=tag))
+                    else:
+                        tmp = self.new_tensor(x.N, 2 * x.H, 2 * x.W, x.C)
+                        self.bwd.append(Launch("mi355_conv2d_igemm", dy, wb, None, tmp, x.N, Ho, Wo, Co, dy.ld, 2 * x.H, 2 * x.W,
+                                               x.C, tmp.ld, k, k, 1, -1, p, s, 0, 0, None, self.code, flops=flops, nbytes=nbytes, tag=tag))
+                        self.bwd.append(Launch("mi355_upsample2_bwd", tmp, tmp.ld, xg, xg.ld, x.N, x.H, x.W, x.C, acc, self.code))
                 else:
                     acc = self.acc_flag(x)
                     xg = self.grad_of(x)

@@ -140,6 +140,36 @@ WG_CASES = [  # N, Ci, H, W, Co, K, stride, pad, up
 ]
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 128, 8, 16, 64), (1, 64, 16, 16, 128), (2, 64, 4, 16, 64)])      # n, co, h, w (input grid), ci
+def test_upsampled_conv_dgrad_with_fused_2x2_sum(shape, dtype):
+    """conv(Upsample(x2)(x)) (AttentionUNet.py:19-20): the data gradient on the up-sampled grid is summed over 2x2 groups
+    in the kernel epilogue (accumulate bit 2) — against autograd through F.interpolate, plain and accumulating."""
+    n, co, h, w_, ci = shape
+    g = torch.Generator().manual_seed(co + h)
+    x = torch.randn(n, ci, h, w_, generator=g, requires_grad=True)
+    w = torch.randn(co, ci, 3, 3, generator=g) / (co * 9) ** 0.5
+    y = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), q(w, dtype), None, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(q(dy, dtype))
+    code = DTYPE_CODE[dtype]
+    assert lib.mi355_conv2d_igemm_variant(2 * h, 2 * w_, co, 2 * h, 2 * w_, ci, 3, 3, 1, -1, 1, 1, 0, code) >= 2
+    _, wb = pack_w(w, dtype)
+    dx = torch.full((n, h, w_, ci), float("nan"), dtype=dtype, device=DEV)
+    lib.mi355_conv2d_igemm(to_nhwc(dy, dtype), wb, None, dx, n, 2 * h, 2 * w_, co, co, 2 * h, 2 * w_, ci, ci, 3, 3, 1, -1, 1, 1, 0, 4,
+                           None, code)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(dx), x.grad) < TOL[dtype]
+    lib.mi355_conv2d_igemm(to_nhwc(dy, dtype), wb, None, dx, n, 2 * h, 2 * w_, co, co, 2 * h, 2 * w_, ci, ci, 3, 3, 1, -1, 1, 1, 0, 5,
+                           None, code)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(dx), 2 * x.grad) < 2 * TOL[dtype]
+    # the kernels without that epilogue refuse the flag (fp32 / 1x1 shapes)
+    with pytest.raises(RuntimeError):
+        lib.mi355_conv2d_igemm(to_nhwc(dy, torch.float32), wb.float(), None, dx.float(), n, 2 * h, 2 * w_, co, co, 2 * h, 2 * w_, ci, ci,
+                               3, 3, 1, -1, 1, 1, 0, 4, None, DTYPE_CODE[torch.float32])
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("case", WG_CASES)
 def test_conv_wgrad(case, dtype):

@@ -251,6 +251,16 @@ int mi355_adaptive_avgpool_fwd(const void* x, int ldx, float* y, int N, int H, i
 int mi355_adaptive_avgpool_bwd(const float* dy, void* dx, int lddx, int N, int H, int W, int C, int OH, int OW, int dtype,
                                mi355_stream_t s);
 
+/* ---- input pipeline on the GPU (utils/trainer.py:52-115 Albumentations transforms; utils/dataset.py:100-134) ----------- */
+/* dst[n][y][x][c] (uint8) = sample of src[n] ([Hs][Ws][C] uint8, C <= 4) at (sx, sy) = m[n] (2x3, row-major) applied to the dst
+ * pixel (x, y): bilinear with cv2's rounding, or nearest; border = replicate (A.Resize) or reflect-101 (A.ShiftScaleRotate). */
+int mi355_warp_u8(const uint8_t* src, int N, int Hs, int Ws, int C, const float* m, uint8_t* dst, int H, int W, int nearest,
+                  int reflect, mi355_stream_t s);
+/* out[n][c][y][x] (fp32 NCHW, what ToTensorV2 yields) = (clip(round(alpha_n*v + beta_n*255)) / 255 - mean[c]) / std[c];
+ * bc = [N][2] (alpha, beta) or NULL (A.RandomBrightnessContrast off); mean == NULL: v / 255 (masks, dataset.py:126). */
+int mi355_normalize_u8(const uint8_t* src, int N, int H, int W, int C, const float* bc, const float* mean, const float* stdv,
+                       float* out, mi355_stream_t s);
+
 /* ---- joint inference pipeline glue (utils/pipeline.py:324-357 classify, 359-418 process_image) ---------- */
 /* pred[b] = argmax_c logits[b][c] (first maximum), conf[b] = 100 * max softmax; kept[0..n_kept) = the batch indices
  * with pred == keep_class, in order.  B <= 1024. */

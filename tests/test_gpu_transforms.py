@@ -1,0 +1,63 @@
+"""-m gpu: the batched GPU input transforms (utils/gpu_transforms.py, csrc/input_pipeline.hip) against the per-sample
+numpy restatement of the reference's Albumentations pipelines (oracle/transforms.py).  Bound: identical uint8 images
+except for <= 0.5 % of the pixels by one grey level (float rounding of a value that sits on .5), i.e. 1/255/std after
+normalisation; masks identical."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import transforms as ot
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _batch(n, hs, ws, seed):
+    g = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:hs, 0:ws]
+    imgs, masks = [], []
+    for i in range(n):      # smooth structure + noise, so that interpolation matters; one ellipse mask per image
+        base = 127 + 90 * np.sin(xx / (7.0 + i)) * np.cos(yy / (5.0 + 2 * i))
+        img = np.clip(base[..., None] + g.normal(0, 12, (hs, ws, 3)), 0, 255).astype(np.uint8)
+        mask = ((((xx - ws * 0.5) / (ws * 0.3)) ** 2 + ((yy - hs * 0.45) / (hs * 0.25)) ** 2) < 1).astype(np.uint8) * 255
+        imgs.append(img); masks.append(mask)
+    return np.stack(imgs), np.stack(masks)
+
+
+def _close(x, ref, tol_levels=1):
+    d = np.abs(x - ref)
+    lim = tol_levels / 255 / ot.IMAGENET_STD.min() * 1.001
+    assert d.max() <= lim, d.max()
+    assert (d > 1e-6).mean() <= 5e-3, (d > 1e-6).mean()
+
+
+@pytest.mark.parametrize("src", [(299, 299), (256, 256), (180, 333)])
+def test_val_transform_matches_oracle(src):
+    from utils.gpu_transforms import SegBatchTransform
+    imgs, masks = _batch(3, src[0], src[1], 1)
+    x, y = SegBatchTransform(256, train=False, device=DEV)(torch.from_numpy(imgs), torch.from_numpy(masks))
+    for i in range(3):
+        xr, yr = ot.val_seg_sample(imgs[i], masks[i][..., None], 256)
+        _close(x[i].cpu().numpy(), xr)
+        assert np.array_equal(y[i].cpu().numpy(), yr)
+    assert set(np.unique(y.cpu().numpy())) <= {0.0, 1.0}
+
+
+def test_train_transform_matches_oracle():
+    from utils.gpu_transforms import SegBatchTransform, shift_scale_rotate_matrix
+    imgs, masks = _batch(4, 299, 299, 2)
+    t = SegBatchTransform(256, train=True, seed=5, device=DEV)
+    draws = [(12.5, 1.04, 0.03, -0.05, True, 1.08, -0.06), (-15.0, 0.95, -0.05, 0.05, False, 0.9, 0.1),
+             (0.0, 1.0, 0.0, 0.0, True, 1.0, 0.0), (7.0, 1.0, 0.02, 0.0, False, 1.1, 0.1)]
+    mats = [shift_scale_rotate_matrix(256, 256, a, s, dx, dy, f) for a, s, dx, dy, f, _, _ in draws]
+    bcs = [[al, be] for *_, al, be in draws]
+    x, y = t(torch.from_numpy(imgs), torch.from_numpy(masks), params=(mats, bcs))
+    for i, (a, s, dx, dy, f, al, be) in enumerate(draws):
+        xr, yr = ot.train_seg_sample(imgs[i], masks[i][..., None], a, s, dx, dy, f, al, be, 256)
+        _close(x[i].cpu().numpy(), xr, tol_levels=2)       # two uint8 roundings in sequence
+        assert (y[i].cpu().numpy() != yr).mean() <= 1e-3   # nearest sampling exactly on a pixel boundary
+    # the random path: reference ranges, reproducible from the seed, masks stay binary
+    x1, y1 = SegBatchTransform(256, train=True, seed=9, device=DEV)(torch.from_numpy(imgs), torch.from_numpy(masks))
+    x2, y2 = SegBatchTransform(256, train=True, seed=9, device=DEV)(torch.from_numpy(imgs), torch.from_numpy(masks))
+    assert torch.equal(x1, x2) and torch.equal(y1, y2) and set(np.unique(y1.cpu().numpy())) <= {0.0, 1.0}
+    assert tuple(x1.shape) == (4, 3, 256, 256) and tuple(y1.shape) == (4, 1, 256, 256)

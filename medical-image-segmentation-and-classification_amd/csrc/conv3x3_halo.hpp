@@ -18,6 +18,8 @@
 // 64-wide) was the round's dominant kernel at 1100 TFLOP/s; the patch-row window below replaced it at +5-8 % on
 // the same layers (+19 % on the 64-wide ones).
 #pragma once
+#include <type_traits>
+
 #include "common.hpp"
 
 // ---- patch-row register window -------------------------------------------------------------------------------------
@@ -75,42 +77,37 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_rw_kernel(const ConvArgs 
   const char* zero = reinterpret_cast<const char*>(g_zero_page);
   const bool flip = a.kmul < 0;                      // data gradient: taps mirrored
 
-  // ---- DMA lane geometry: a 1-KiB instruction = 16 patch pixels x 64 B; a wave issues instruction wave + 4*i while it is < P_INSTR ----
+  // ---- DMA lane geometry: a 1-KiB instruction = 16 patch pixels x 64 B; wave w issues pieces w, w+4, ... (P_IT of them; a
+  // piece index past the patch repeats the last piece: same bytes to the same place, so every wave issues the same count) ----
   const int lrow = lane >> 2, slot = lane & 3;
-  const bool short_last = wave + 4 * (P_IT - 1) >= P_INSTR;       // this wave issues P_IT - 1 patch instructions
   const T* p_src[P_IT];
+  int p_dst[P_IT];
 #pragma unroll
   for (int i = 0; i < P_IT; ++i) {
-    const int q = (wave + 4 * i) * 16 + lrow;
+    const int piece = min(wave + 4 * i, P_INSTR - 1);
+    const int q = piece * 16 + lrow;
     const int py = q / PW, px = q - py * PW;
     const int yy = y0 - 1 + py, xx = x0 - 1 + px;
     const bool ok = q < NPIX && (unsigned)yy < (unsigned)a.Hlog && (unsigned)xx < (unsigned)a.Wlog;
     p_src[i] = ok ? in + ((size_t)(n * a.Hi + (yy >> a.up)) * a.Wi + (xx >> a.up)) * a.ldi + (slot ^ (((q >> 2) & 1) << 1)) * EPC
                   : nullptr;
+    p_dst[i] = piece * 1024;
   }
   unsigned char* const patch0 = lds;
   unsigned char* const bring = lds + 2 * PATCH_BYTES;
-  auto issue_patch = [&](int buf, int c0) {
-    unsigned char* dst = patch0 + buf * PATCH_BYTES;
-#pragma unroll
-    for (int i = 0; i < P_IT; ++i) {
-      if (i == P_IT - 1 && short_last) break;
-      const char* p = p_src[i] ? reinterpret_cast<const char*>(p_src[i] + c0) : zero + slot * 16;
-      dma16(p, lds_addr(dst + (wave + 4 * i) * 1024));
-    }
+  auto issue_patch_piece = [&](int buf, int c0, int i) {
+    const char* p = p_src[i] ? reinterpret_cast<const char*>(p_src[i] + c0) : zero + slot * 16;
+    dma16(p, lds_addr(patch0 + buf * PATCH_BYTES + p_dst[i]));
   };
   // stage = the three taps of patch column pw: slab ph holds tap (ph, pw), mirrored for the data gradient; a wave
   // brings 16 rows x 64 B of each slab (one instruction per slab)
   const size_t wrow = (size_t)9 * a.Ci;
   const int brow = wave * 16 + lrow;
   const T* const b_src = wk + (size_t)(n0 + brow) * wrow + (slot ^ (((brow >> 2) & 1) << 1)) * EPC;
-  auto issue_stage = [&](int stage, int pw, int c0) {
-    unsigned char* dst = bring + stage * STAGE + wave * 1024;
-#pragma unroll
-    for (int ph = 0; ph < 3; ++ph) {
-      const int tap = flip ? (2 - ph) * 3 + (2 - pw) : ph * 3 + pw;
-      dma16(b_src + (size_t)tap * a.Ci + c0, lds_addr(dst + ph * SLAB));
-    }
+  auto issue_stage_piece = [&](int stage, int pw, int c0, int ph) {      // c0 < 0: nothing left to fetch (zeros into a dead slot)
+    const int tap = flip ? (2 - ph) * 3 + (2 - pw) : ph * 3 + pw;
+    const char* p = c0 >= 0 ? reinterpret_cast<const char*>(b_src + (size_t)tap * a.Ci + c0) : zero + slot * 16;
+    dma16(p, lds_addr(bring + stage * STAGE + wave * 1024 + ph * SLAB));
   };
 
   // ---- fragment geometry ------------------------------------------------------------------------------------------
@@ -128,81 +125,75 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_rw_kernel(const ConvArgs 
     for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nC = a.Ci / BK;
-  const int S = nC * 3;                              // steps = (chunk, patch column)
-  int ipw = 0, ic0 = 0, issued = 0, istage = 0;
-  auto issue_next = [&]() {
-    issue_stage(istage, ipw, ic0);
-    istage = (istage + 1 == NS) ? 0 : istage + 1;
-    if (++ipw == 3) {
-      ipw = 0;
-      ic0 += BK;
-    }
-    ++issued;
-  };
-  issue_patch(0, 0);
-  issue_next();
-  issue_next();                                      // S >= 3
+  // prologue: patch of chunk 0 and the stages of steps 0 and 1 (stage index == patch column: three steps per chunk)
+#pragma unroll
+  for (int i = 0; i < P_IT; ++i) issue_patch_piece(0, 0, i);
+#pragma unroll
+  for (int ph = 0; ph < 3; ++ph) issue_stage_piece(0, 0, 0, ph);
+#pragma unroll
+  for (int ph = 0; ph < 3; ++ph) issue_stage_piece(1, 1, 0, ph);
   wait_vmcnt<B_IT>();
   __builtin_amdgcn_s_barrier();
 
-  int stage = 0, pw = 0, chunk = 0;
-  for (int s = 0; s < S; ++s) {
-    const bool more_b = issued < S;
-    if (more_b) issue_next();
-    const bool patch_now = pw == 0 && chunk + 1 < nC;
-    if (patch_now) issue_patch((chunk + 1) & 1, (chunk + 1) * BK);
-
+  // One step = patch column pw of chunk `chunk` (48 MFMAs per wave).  Every DMA instruction of the step — the stage two steps
+  // ahead, and in column 0 the next chunk's patch — is issued from INSIDE the MFMA stream, a piece after each patch row's
+  // MFMAs, so that its address arithmetic and m0 traffic run in the shadow of the matrix pipe instead of in front of it.
+  auto step = [&](int chunk, auto pw_tag) {
+    constexpr int pw = decltype(pw_tag)::value;
+    constexpr int NPIECE = B_IT + (pw == 0 ? P_IT : 0);
+    constexpr int NPR = RW + 2;
+    // the stage two steps ahead: (chunk, pw + 2) or (chunk + 1, pw - 1); nothing past the last step
+    constexpr int pw2 = (pw + 2) % 3;
+    const int c2 = (pw == 0 ? chunk : chunk + 1);
+    const int c0_stage = c2 < nC ? c2 * BK : -1;
+    const bool next_patch = chunk + 1 < nC;
     const unsigned char* pa = patch0 + (chunk & 1) * PATCH_BYTES;
-    const unsigned char* pb = bring + stage * STAGE;
+    const unsigned char* pb = bring + pw * STAGE;
     bf16x8 bfr[3][NB];
 #pragma unroll
     for (int ph = 0; ph < 3; ++ph)
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) bfr[ph][nb] = *reinterpret_cast<const bf16x8*>(pb + ph * SLAB + boff[nb]);
-    bf16x8 afr[RW + 2][XB];
+    bf16x8 afr[NPR][XB];
 #pragma unroll
-    for (int pr = 0; pr < RW + 2; ++pr)
+    for (int pr = 0; pr < NPR; ++pr)
 #pragma unroll
       for (int xb = 0; xb < XB; ++xb) {
         const int q = q00 + pr * PW + xb * 16 + pw;
         afr[pr][xb] = *reinterpret_cast<const bf16x8*>(pa + q * PIXB + ((c4 ^ (((q >> 2) & 1) << 1)) << 4));
       }
+    __builtin_amdgcn_sched_barrier(0);              // every fragment read of the step is in flight before the first MFMA
 #pragma unroll
-    for (int pr = 0; pr < RW + 2; ++pr)
+    for (int pr = 0; pr < NPR; ++pr) {
 #pragma unroll
       for (int xb = 0; xb < XB; ++xb)
 #pragma unroll
         for (int ph = 0; ph < 3; ++ph) {
-          const int orow = pr - ph;                    // output row of this wave served through patch-row offset ph
+          const int orow = pr - ph;                  // output row of this wave served through patch-row offset ph
           if (orow >= 0 && orow < RW) {
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
               acc[orow * XB + xb][nb] = mfma_16x16x32<T>(afr[pr][xb], bfr[ph][nb], acc[orow * XB + xb][nb]);
           }
         }
-    // registers are plentiful at this tile width (64 accumulators): every fragment read of the step is issued first,
-    // the 48 MFMAs then wait with counted lgkmcnt for exactly the operands they need (+2 % over the compiler's order)
-    __builtin_amdgcn_sched_group_barrier(0x100, 3 * NB + (RW + 2) * XB, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 3 * NB * RW * XB, 0);
-    // stage s+1 (and, in order before it, any older patch) must have landed; what may stay in flight: the stage
-    // issued this step and a patch issued this step or the one before
-    const bool patch_pending = (pw <= 1) && chunk + 1 < nC;
-    if (more_b) {
-      if (patch_pending) {
-        if (short_last) wait_vmcnt<B_IT + P_IT - 1>(); else wait_vmcnt<B_IT + P_IT>();
-      } else {
-        wait_vmcnt<B_IT>();
+#pragma unroll
+      for (int k = pr * NPIECE / NPR; k < (pr + 1) * NPIECE / NPR; ++k) {
+        if (k < B_IT) issue_stage_piece(pw2, pw2, c0_stage, k);
+        else issue_patch_piece((chunk + 1) & 1, next_patch ? (chunk + 1) * BK : chunk * BK, k - B_IT);      // (last chunk: a dead buffer)
       }
-    } else {
-      wait_vmcnt<0>();
+      __builtin_amdgcn_sched_barrier(0);
     }
+    // stage s+1 (and, in order before it, the patch issued in column 0) must have landed; what may stay in flight: the
+    // stage issued this step, and the patch issued in this column-0 step or the one before
+    if (pw <= 1) wait_vmcnt<B_IT + P_IT>(); else wait_vmcnt<B_IT>();
     __builtin_amdgcn_s_barrier();
-    stage = (stage + 1 == NS) ? 0 : stage + 1;
-    if (++pw == 3) {
-      pw = 0;
-      ++chunk;
-    }
+  };
+  for (int chunk = 0; chunk < nC; ++chunk) {
+    step(chunk, std::integral_constant<int, 0>{});
+    step(chunk, std::integral_constant<int, 1>{});
+    step(chunk, std::integral_constant<int, 2>{});
   }
+  wait_vmcnt<0>();                                   // (the zero-fill pieces of the last two steps)
 
   // ---- epilogue: bias, fused BN partial sums of the ROUNDED outputs, C tile staged through LDS for 16-B row-contiguous stores ----
   T* __restrict__ out = reinterpret_cast<T*>(a.out);

@@ -153,19 +153,20 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args 
     load_dy(ZERO_IMG, dm);
     // one row step; `xa` holds X(r)[kw = 0]; on return `xb` holds X(r+1)[kw = 0]
     auto row_step = [&](int r, bf16x8 (&xa)[2], bf16x8 (&xb)[2]) {
-      const bool more = r + 3 <= yb;               // rows up to yb (the bottom halo) are ever needed
-      if (more) issue_row(r + 3, (xs + 3) & (NRX - 1), wrap(d + 3, NRD));
       load_x(xs, 1, xb);
       mfma12(0, xa);
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);      // the next tap column's fragments first, then this one's MFMAs
       __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+      // row r+3 is fetched from inside the MFMA stream (its address arithmetic runs in the matrix pipe's shadow), always:
+      // past the band it brings zeros / unused rows into ring slots that are dead by then, which keeps vmcnt uniform
+      issue_row(r + 3, (xs + 3) & (NRX - 1), wrap(d + 3, NRD));
       load_x(xs, 2, xa);
       mfma12(1, xb);
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
       __builtin_amdgcn_sched_group_barrier(0x008, 12, 1);
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every read of X row r has returned: its slot is reused by row r+4
-      if (more) wait_vmcnt<3>(); else wait_vmcnt<0>();         // rows <= r+2 have landed
+      wait_vmcnt<3>();                                        // rows <= r+2 have landed
       __builtin_amdgcn_s_barrier();
       const int on = r + 2 < yb ? X_BYTES + wrap(d + 2, NRD) * DROW : ZERO_IMG;      // dY row r+2 (or the zero image)
       xs = (xs + 1) & (NRX - 1);
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args 
       row_step(r + 1, xb, xa);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wait_vmcnt<0>();                               // (the trailing rows issued past the band)
     __builtin_amdgcn_s_barrier();                  // the next item's DMA overwrites the slots read last
   }
 

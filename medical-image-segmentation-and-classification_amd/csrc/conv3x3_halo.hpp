@@ -118,6 +118,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_rw_kernel(const ConvArgs 
     const int row = wn * WTN + nb * 16 + l16;
     boff[nb] = row * PIXB + ((c4 ^ (((row >> 2) & 1) << 1)) << 4);
   }
+  // byte offset of every pixel fragment this lane ever reads inside a patch buffer: [patch column][patch row][x block]
+  // (36 registers; the main loop then issues its LDS reads without any address arithmetic in front of the MFMAs)
+  int aoff[3][RW + 2][XB];
+#pragma unroll
+  for (int pw = 0; pw < 3; ++pw)
+#pragma unroll
+    for (int pr = 0; pr < RW + 2; ++pr)
+#pragma unroll
+      for (int xb = 0; xb < XB; ++xb) {
+        const int q = q00 + pr * PW + xb * 16 + pw;
+        aoff[pw][pr][xb] = q * PIXB + ((c4 ^ (((q >> 2) & 1) << 1)) << 4);
+      }
   f32x4 acc[MB][NB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
@@ -138,8 +150,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_rw_kernel(const ConvArgs 
   // One step = patch column pw of chunk `chunk` (48 MFMAs per wave).  Every DMA instruction of the step — the stage two steps
   // ahead, and in column 0 the next chunk's patch — is issued from INSIDE the MFMA stream, a piece after each patch row's
   // MFMAs, so that its address arithmetic and m0 traffic run in the shadow of the matrix pipe instead of in front of it.
-  auto step = [&](int chunk, auto pw_tag) {
+  auto step = [&](int chunk, auto pw_tag, auto par_tag) {
     constexpr int pw = decltype(pw_tag)::value;
+    constexpr int par = decltype(par_tag)::value;      // chunk & 1: the patch buffer is a compile-time LDS offset
     constexpr int NPIECE = B_IT + (pw == 0 ? P_IT : 0);
     constexpr int NPR = RW + 2;
     // the stage two steps ahead: (chunk, pw + 2) or (chunk + 1, pw - 1); nothing past the last step
@@ -147,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_rw_kernel(const ConvArgs 
     const int c2 = (pw == 0 ? chunk : chunk + 1);
     const int c0_stage = c2 < nC ? c2 * BK : -1;
     const bool next_patch = chunk + 1 < nC;
-    const unsigned char* pa = patch0 + (chunk & 1) * PATCH_BYTES;
+    const unsigned char* pa = patch0 + par * PATCH_BYTES;
     const unsigned char* pb = bring + pw * STAGE;
     bf16x8 bfr[3][NB];
 #pragma unroll
@@ -158,10 +171,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_rw_kernel(const ConvArgs 
 #pragma unroll
     for (int pr = 0; pr < NPR; ++pr)
 #pragma unroll
-      for (int xb = 0; xb < XB; ++xb) {
-        const int q = q00 + pr * PW + xb * 16 + pw;
-        afr[pr][xb] = *reinterpret_cast<const bf16x8*>(pa + q * PIXB + ((c4 ^ (((q >> 2) & 1) << 1)) << 4));
-      }
+      for (int xb = 0; xb < XB; ++xb) afr[pr][xb] = *reinterpret_cast<const bf16x8*>(pa + aoff[pw][pr][xb]);
     __builtin_amdgcn_sched_barrier(0);              // every fragment read of the step is in flight before the first MFMA
 #pragma unroll
     for (int pr = 0; pr < NPR; ++pr) {
@@ -179,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_rw_kernel(const ConvArgs 
 #pragma unroll
       for (int k = pr * NPIECE / NPR; k < (pr + 1) * NPIECE / NPR; ++k) {
         if (k < B_IT) issue_stage_piece(pw2, pw2, c0_stage, k);
-        else issue_patch_piece((chunk + 1) & 1, next_patch ? (chunk + 1) * BK : chunk * BK, k - B_IT);      // (last chunk: a dead buffer)
+        else issue_patch_piece(par ^ 1, next_patch ? (chunk + 1) * BK : chunk * BK, k - B_IT);      // (last chunk: a dead buffer)
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -188,10 +198,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_rw_kernel(const ConvArgs 
     if (pw <= 1) wait_vmcnt<B_IT + P_IT>(); else wait_vmcnt<B_IT>();
     __builtin_amdgcn_s_barrier();
   };
-  for (int chunk = 0; chunk < nC; ++chunk) {
-    step(chunk, std::integral_constant<int, 0>{});
-    step(chunk, std::integral_constant<int, 1>{});
-    step(chunk, std::integral_constant<int, 2>{});
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  for (int chunk = 0; chunk < nC; chunk += 2) {
+    step(chunk, I0{}, I0{});
+    step(chunk, I1{}, I0{});
+    step(chunk, I2{}, I0{});
+    if (chunk + 1 < nC) {
+      step(chunk + 1, I0{}, I1{});
+      step(chunk + 1, I1{}, I1{});
+      step(chunk + 1, I2{}, I1{});
+    }
   }
   wait_vmcnt<0>();                                   // (the zero-fill pieces of the last two steps)
 

@@ -162,28 +162,33 @@ template <typename T> struct BnActOp {
       if (x2) sh[e] += shift2[c0 + e];
     }
   }
-  __device__ void apply(size_t row, int c0) const {
-    const Vec16<T> v = ld16<T>(x + row * ldx + c0);
+  static constexpr int FETCH_ROWS = 8;
+  struct In { Vec16<T> v, v2, vr; };
+  __device__ In fetch(size_t row, int c0) const {
+    In in;
+    in.v = ld16<T>(x + row * ldx + c0);
+    if (x2) in.v2 = ld16<T>(x2 + row * ldx2 + c0);
+    if (res) in.vr = ld16<T>(res + row * ldr + c0);
+    return in;
+  }
+  __device__ void finish(const In& in, size_t row, int c0) const {
     float f[EPC];
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) f[e] = to_f32<T>(v.v[e]) * sc[e] + sh[e];
+    for (int e = 0; e < EPC; ++e) f[e] = to_f32<T>(in.v.v[e]) * sc[e] + sh[e];
     if (x2) {
-      const Vec16<T> v2 = ld16<T>(x2 + row * ldx2 + c0);
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) f[e] += to_f32<T>(v2.v[e]) * sc2[e];
+      for (int e = 0; e < EPC; ++e) f[e] += to_f32<T>(in.v2.v[e]) * sc2[e];
     }
     // act bit0: ReLU; bit1: the residual is added AFTER the activation (recurrent block x + relu(bn(.)),
     // R2AttU_Net.py:44) instead of before it (ResNet.py:43)
     const bool relu = act & 1, post = act & 2;
-    Vec16<T> vr;
-    if (res) vr = ld16<T>(res + row * ldr + c0);
     Vec16<T> o;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
       float v = f[e];
-      if (res && !post) v += to_f32<T>(vr.v[e]);
+      if (res && !post) v += to_f32<T>(in.vr.v[e]);
       if (relu) v = fmaxf(v, 0.f);
-      if (res && post) v += to_f32<T>(vr.v[e]);
+      if (res && post) v += to_f32<T>(in.vr.v[e]);
       o.v[e] = from_f32<T>(v);
     }
     st16<T>(y + row * ldy + c0, o);
@@ -220,17 +225,22 @@ template <typename T> struct BnBwdReduceOp {
       mt[e] = (act && !y) ? mshift[c0 + e] : 0.f;
     }
   }
-  __device__ void apply(size_t row, int c0, Acc (&acc)[NQ][EPC]) const {
-    const Vec16<T> g = ld16<T>(dy + row * lddy + c0);
-    const Vec16<T> xv = ld16<T>(x + row * ldx + c0);
-    Vec16<T> yv;
-    if (act && y) yv = ld16<T>(y + row * ldy + c0);
+  static constexpr int FETCH_ROWS = 4;
+  struct In { Vec16<T> g, xv, yv; };
+  __device__ In fetch(size_t row, int c0) const {
+    In in;
+    in.g = ld16<T>(dy + row * lddy + c0);
+    in.xv = ld16<T>(x + row * ldx + c0);
+    if (act && y) in.yv = ld16<T>(y + row * ldy + c0);
+    return in;
+  }
+  __device__ void finish(const In& in, size_t, int, Acc (&acc)[NQ][EPC]) const {
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
-      float gg = to_f32<T>(g.v[e]);
-      const float xf = to_f32<T>(xv.v[e]);
+      float gg = to_f32<T>(in.g.v[e]);
+      const float xf = to_f32<T>(in.xv.v[e]);
       if (act) {
-        const bool on = y ? (to_f32<T>(yv.v[e]) > 0.f) : (xf * ms[e] + mt[e] > 0.f);
+        const bool on = y ? (to_f32<T>(in.yv.v[e]) > 0.f) : (xf * ms[e] + mt[e] > 0.f);
         if (!on) gg = 0.f;
       }
       acc[0][e] += gg;
@@ -294,18 +304,23 @@ template <typename T> struct BnBwdApplyOp {
       k1[e] = sums[C + c0 + e] * invM;
     }
   }
-  __device__ void apply(size_t row, int c0, Acc (&acc)[NQ][EPC]) const {
-    const Vec16<T> g = ld16<T>(dy + row * lddy + c0);
-    const Vec16<T> xv = ld16<T>(x + row * ldx + c0);
-    Vec16<T> yv;
-    if (act && y) yv = ld16<T>(y + row * ldy + c0);
+  static constexpr int FETCH_ROWS = 4;
+  struct In { Vec16<T> g, xv, yv; };
+  __device__ In fetch(size_t row, int c0) const {
+    In in;
+    in.g = ld16<T>(dy + row * lddy + c0);
+    in.xv = ld16<T>(x + row * ldx + c0);
+    if (act && y) in.yv = ld16<T>(y + row * ldy + c0);
+    return in;
+  }
+  __device__ void finish(const In& in, size_t row, int c0, Acc (&acc)[NQ][EPC]) const {
     Vec16<T> o, r;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
-      float gg = to_f32<T>(g.v[e]);
-      const float xf = to_f32<T>(xv.v[e]);
+      float gg = to_f32<T>(in.g.v[e]);
+      const float xf = to_f32<T>(in.xv.v[e]);
       if (act) {
-        const bool on = y ? (to_f32<T>(yv.v[e]) > 0.f) : (xf * ms[e] + mt[e] > 0.f);
+        const bool on = y ? (to_f32<T>(in.yv.v[e]) > 0.f) : (xf * ms[e] + mt[e] > 0.f);
         if (!on) gg = 0.f;
       }
       const float xh = (xf - mu[e]) * is[e];

@@ -7,6 +7,7 @@
 // workgroup:  partial[(block*NQ + q)*C + c].  A tiny finalize kernel sums the partials in a
 // fixed order (deterministic, no float atomics).
 #pragma once
+#include <type_traits>
 #include "common.hpp"
 
 #define MI355_RR_MAX_BLOCKS 1024
@@ -39,6 +40,11 @@ static inline RowRedGeom rowred_geom(long long M, int C, int nblocks) {
   return g;
 }
 
+// An op may split apply() into `In fetch(row, c0) const` (loads only) and `finish(in, row, c0[, acc])` (arithmetic and stores),
+// with `static constexpr int FETCH_ROWS`: the kernels then fetch that many rows before finishing any of them.
+template <typename Op, typename = void> struct has_fetch : std::false_type {};
+template <typename Op> struct has_fetch<Op, std::void_t<typename Op::In>> : std::true_type {};
+
 // Op contract:
 //   static constexpr int NQ;                       number of reduced quantities
 //   static constexpr bool WRITES;                  apply() also stores an output tensor
@@ -66,7 +72,25 @@ __global__ __launch_bounds__(256) void rowred_kernel(Op op, RowRedGeom g, float*
     const long long r0 = (long long)blockIdx.x * g.rows_per_block;
     long long r1 = r0 + g.rows_per_block;
     if (r1 > g.M) r1 = g.M;
-    if constexpr (!Op::WRITES && sizeof(typename Op::Acc) == 4) {
+    if constexpr (has_fetch<Op>::value) {
+      // ops that also store: the compiler may not move a load above the previous row's store (the tensors can alias), so
+      // the rows of a trip are fetched explicitly before any of them is finished — FETCH_ROWS x the bytes in flight
+      // A workgroup pass covers B * rp consecutive rows and the grid sweeps the tensor as one moving window (workgroups that
+      // each own a far-apart contiguous band were measured slower: see DESIGN.md, streaming kernels).
+      constexpr int B = Op::FETCH_ROWS;
+      const long long st = (long long)gridDim.x * g.rp * B;
+      for (long long r = (long long)blockIdx.x * g.rp * B + ty; r < g.M; r += st) {
+        if (r + (long long)(B - 1) * g.rp < g.M) {
+          typename Op::In in[B];
+#pragma unroll
+          for (int b = 0; b < B; ++b) in[b] = op.fetch((size_t)(r + (long long)b * g.rp), c0);
+#pragma unroll
+          for (int b = 0; b < B; ++b) op.finish(in[b], (size_t)(r + (long long)b * g.rp), c0, acc);
+        } else {
+          for (long long q = r; q < g.M; q += g.rp) op.finish(op.fetch((size_t)q, c0), (size_t)q, c0, acc);
+        }
+      }
+    } else if constexpr (!Op::WRITES && sizeof(typename Op::Acc) == 4) {
       // read-only reductions: two rows per trip keep twice the bytes in flight (+5 % on bn_bwd_reduce; ops that also
       // store — bn_bwd_apply — were measured slower with it)
 #pragma unroll 2
@@ -137,7 +161,25 @@ __global__ __launch_bounds__(256) void rowmap_kernel(Op op, long long M, int cp)
   if (ty >= rp) return;
   for (int c = tx; c < cp; c += tpr) {          // one trip unless a row has more than 256 chunks
     op.load_cols(c * EPC);                       // per-channel constants live in registers for the whole band
-    for (long long r = (long long)blockIdx.x * rp + ty; r < M; r += (long long)gridDim.x * rp) op.apply((size_t)r, c * EPC);
+    if constexpr (has_fetch<Op>::value) {        // (see rowred_kernel: explicit fetch-then-finish batches)
+      // a workgroup pass covers B * rp CONSECUTIVE rows (thread rows r, r + rp, ...): the chip still sweeps the tensor as one
+      // moving window (batches a grid stride apart were measured 18 % slower than no batching at all)
+      constexpr int B = Op::FETCH_ROWS;
+      const long long st = (long long)gridDim.x * rp * B;
+      for (long long r = (long long)blockIdx.x * rp * B + ty; r < M; r += st) {
+        if (r + (long long)(B - 1) * rp < M) {
+          typename Op::In in[B];
+#pragma unroll
+          for (int b = 0; b < B; ++b) in[b] = op.fetch((size_t)(r + b * rp), c * EPC);
+#pragma unroll
+          for (int b = 0; b < B; ++b) op.finish(in[b], (size_t)(r + b * rp), c * EPC);
+        } else {
+          for (long long q = r; q < M; q += rp) op.finish(op.fetch((size_t)q, c * EPC), (size_t)q, c * EPC);
+        }
+      }
+    } else {
+      for (long long r = (long long)blockIdx.x * rp + ty; r < M; r += (long long)gridDim.x * rp) op.apply((size_t)r, c * EPC);
+    }
   }
 }
 
@@ -150,7 +192,9 @@ static inline int rowmap_launch(const Op& op, long long M, int C, hipStream_t s)
   }
   const int cp = C / epc;
   const int rp = 256 / (cp < 256 ? cp : 256);
-  long long blocks = (M + rp - 1) / rp;
+  long long rpb = rp;
+  if constexpr (has_fetch<Op>::value) rpb *= Op::FETCH_ROWS;
+  long long blocks = (M + rpb - 1) / rpb;
   if (blocks > 256 * 16) blocks = 256 * 16;     // grid-stride beyond 16 workgroups per CU
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL((rowmap_kernel<T, Op>), dim3((int)blocks), dim3(256), 0, s, op, M, cp);

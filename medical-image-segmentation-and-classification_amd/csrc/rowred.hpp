@@ -25,6 +25,7 @@ struct RowRedGeom {
   int rows_per_block;
   int tpr;   // threads per row (<= 256)
   int rp;    // rows walked in parallel by one block
+  int nb_rows;   // rows of `partial` the caller folds (== rowreduce_blocks(M)); rows past the grid are written as zeros
 };
 
 template <typename T>
@@ -126,6 +127,11 @@ __global__ __launch_bounds__(256) void rowred_kernel(Op op, RowRedGeom g, float*
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
       for (int e = 0; e < EPC; ++e) partial[((size_t)blockIdx.x * NQ + q) * g.C + c0 + e] = (float)acc[q][e];
+    for (int b = blockIdx.x + gridDim.x; b < g.nb_rows; b += gridDim.x)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) partial[((size_t)b * NQ + q) * g.C + c0 + e] = 0.f;
   }
 }
 
@@ -136,8 +142,14 @@ static inline int rowred_launch(const Op& op, long long M, int C, float* partial
     mi355_set_error("row reduction: C=%d must be a multiple of %d", C, epc);
     return MI355_ERR_ARG;
   }
-  const int nb = rowreduce_blocks(M);
-  const RowRedGeom g = rowred_geom<T>(M, C, nb);
+  // The caller sized `partial` (and tells the finalize kernels) rowreduce_blocks(M) rows.  Ops that keep several rows in
+  // flight per thread stream faster from ONE workgroup per CU (bn_bwd_apply 256^2 x 64: 1024 / 512 / 256 workgroups =
+  // 4.97 / 5.03 / 5.35 TB/s); the rows of `partial` they do not produce are zero-filled.
+  const int nb_rows = rowreduce_blocks(M);
+  int nb = nb_rows;
+  if constexpr (has_fetch<Op>::value) nb = nb < 256 ? nb : 256;
+  RowRedGeom g = rowred_geom<T>(M, C, nb);
+  g.nb_rows = nb_rows;
   const int cp = C / epc;
   dim3 grid(nb, (cp + 255) / 256);
   hipLaunchKernelGGL((rowred_kernel<T, Op>), grid, dim3(256), 0, s, op, g, partial);
@@ -195,7 +207,10 @@ static inline int rowmap_launch(const Op& op, long long M, int C, hipStream_t s)
   long long rpb = rp;
   if constexpr (has_fetch<Op>::value) rpb *= Op::FETCH_ROWS;
   long long blocks = (M + rpb - 1) / rpb;
-  if (blocks > 256 * 16) blocks = 256 * 16;     // grid-stride beyond 16 workgroups per CU
+  // grid-stride beyond 16 workgroups per CU; ops that keep several rows in flight per thread stream faster from 4 per CU
+  // (bn_act 256^2 x 64: 4096 / 1024 / 512 workgroups = 4.18 / 4.45 / 4.45 TB/s)
+  const long long cap = has_fetch<Op>::value ? 256 * 4 : 256 * 16;
+  if (blocks > cap) blocks = cap;     // grid-stride beyond 16 workgroups per CU
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL((rowmap_kernel<T, Op>), dim3((int)blocks), dim3(256), 0, s, op, M, cp);
   hipError_t e = hipGetLastError();

@@ -121,6 +121,9 @@ int mi355_bn_finalize(const float* partial, int nblocks, long long M, int C, con
                       const float* beta, float* running_mean, float* running_var, int64_t* nbt,
                       float momentum, float eps, float* scale, float* shift, float* mean, float* invstd,
                       mi355_stream_t s);
+/* out[j][c] = sum of partial rows [j*per, (j+1)*per) (per = ceil(rows / nsplit)), c < rowlen: pre-folds the one-row-per-tile
+ * statistics a convolution epilogue leaves (thousands of rows) so that mi355_bn_finalize reads nsplit rows. */
+int mi355_fold_rows(const float* partial, int rows, int rowlen, float* out, int nsplit, mi355_stream_t s);
 /* Eval-mode scale/shift from running stats. */
 /* out[c] = scale[c] * (bias ? bias[c] : 0) + shift[c]: the bias of a convolution with eval-mode BN folded in. */
 int mi355_bn_fold_bias(const float* bias, const float* scale, const float* shift, float* out, int C, mi355_stream_t s);

@@ -113,6 +113,38 @@ extern "C" int mi355_bn_finalize(const float* partial, int nblocks, long long M,
   return MI355_OK;
 }
 
+// One wave row = 64 consecutive floats of a partial row (256 B); four row lanes per workgroup, four loads in flight per lane.
+__global__ __launch_bounds__(256) void fold_rows_kernel(const float* __restrict__ in, int rows, int rowlen, float* __restrict__ out,
+                                                        int nsplit) {
+  __shared__ double red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int per = (rows + nsplit - 1) / nsplit;
+  const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  if (c < rowlen) {
+    int r = r0 + rl;
+    for (; r + 12 < r1; r += 16) {
+      s0 += (double)in[(size_t)r * rowlen + c];
+      s1 += (double)in[(size_t)(r + 4) * rowlen + c];
+      s2 += (double)in[(size_t)(r + 8) * rowlen + c];
+      s3 += (double)in[(size_t)(r + 12) * rowlen + c];
+    }
+    for (; r < r1; r += 4) s0 += (double)in[(size_t)r * rowlen + c];
+  }
+  red[rl][cl] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rl == 0 && c < rowlen) out[(size_t)blockIdx.y * rowlen + c] = (float)((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]));
+}
+
+extern "C" int mi355_fold_rows(const float* partial, int rows, int rowlen, float* out, int nsplit, mi355_stream_t s) {
+  MI355_CHECK_ARG(partial && out && rows > 0 && rowlen > 0 && nsplit > 0 && nsplit <= rows, "fold_rows: bad arguments");
+  hipLaunchKernelGGL(fold_rows_kernel, dim3(ceil_div(rowlen, 64), nsplit), dim3(256), 0, (hipStream_t)s, partial, rows, rowlen, out,
+                     nsplit);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
 __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
                                       int C, float* scale, float* shift) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;

@@ -503,6 +503,10 @@ class Builder:
             if fused_rows > 0:
                 nb = fused_rows
                 part = self.ws_f32(nb * 2 * C)
+                if nb > 2048:       # one row per conv tile (4 MB of partials at 256^2): pre-fold to 64 rows with a wide grid
+                    folded = self.f32(64 * 2 * C)
+                    self.fwd.append(Launch("mi355_fold_rows", part, nb, 2 * C, folded, 64))
+                    part, nb = folded, 64
             else:
                 nb = lib.mi355_rowreduce_blocks(y.M)
                 part = self.ws_f32(nb * 2 * C)

@@ -51,6 +51,20 @@ def test_bn_forward_train(shape, dtype):
     assert rel_err(isd.cpu(), 1 / torch.sqrt(x.var((0, 2, 3), unbiased=False) + 1e-5)) < 1e-5
 
 
+@pytest.mark.parametrize("rows,rowlen,nsplit", [(8192, 128, 64), (2049, 130, 64), (100, 7, 3), (5, 64, 5)])
+def test_fold_rows(rows, rowlen, nsplit):
+    """mi355_fold_rows: out[j] = sum of the j-th band of ceil(rows / nsplit) partial rows (a short or empty last band too)."""
+    g = torch.Generator().manual_seed(rows)
+    part = torch.randn(rows, rowlen, generator=g)
+    out = torch.full((nsplit, rowlen), float("nan"), device=DEV)
+    lib.mi355_fold_rows(dev(part), rows, rowlen, out, nsplit)
+    torch.cuda.synchronize()
+    per = -(-rows // nsplit)
+    ref = torch.stack([part[j * per:(j + 1) * per].double().sum(0) for j in range(nsplit)]).float()
+    assert torch.allclose(out.cpu(), ref, rtol=1e-6, atol=1e-6)
+    assert rel_err(out.cpu().double().sum(0), part.double().sum(0)) < 1e-6
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("act,with_res", [(1, False), (0, False), (1, True)])
 def test_bn_backward(dtype, act, with_res):

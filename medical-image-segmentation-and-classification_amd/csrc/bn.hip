@@ -103,7 +103,9 @@ extern "C" int mi355_bn_finalize(const float* partial, int nblocks, long long M,
                                  float momentum, float eps, float* scale, float* shift, float* mean, float* invstd,
                                  mi355_stream_t s) {
   MI355_CHECK_ARG(partial && gamma && beta && scale && shift && mean && invstd, "bn_finalize: null pointer");
-  if (nblocks > 2048)
+  // many partial rows: 4 channels x 256 row lanes per workgroup (C/4 workgroups, at most 4 dependent loads per thread for the
+  // 1024 rows of a row reduction); few rows: 32 x 32
+  if (nblocks > 128)
     hipLaunchKernelGGL((bn_finalize_kernel<4, 256>), dim3(ceil_div(C, 4)), dim3(1024), 0, (hipStream_t)s, partial, nblocks, (double)M, C,
                        gamma, beta, running_mean, running_var, nbt, momentum, eps, scale, shift, mean, invstd);
   else
@@ -292,13 +294,15 @@ extern "C" int mi355_bn_bwd_reduce(const void* dy, int lddy, const void* y, int 
   });
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, float* __restrict__ sums,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float accf) {
-  __shared__ double red[32 * 32];
-  const double s0 = fold_partials<32, 32>(partial, nblocks, 2 * C, 0, C, red);
-  const double s1 = fold_partials<32, 32>(partial, nblocks, 2 * C, C, C, red);
-  const int c = blockIdx.x * 32 + threadIdx.x;
-  if (threadIdx.x >= 32 || c >= C) return;
+template <int CH, int BL>
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int C,
+                                                               float* __restrict__ sums, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, float accf) {
+  __shared__ double red[CH * BL];
+  const double s0 = fold_partials<CH, BL>(partial, nblocks, 2 * C, 0, C, red);
+  const double s1 = fold_partials<CH, BL>(partial, nblocks, 2 * C, C, C, red);
+  const int c = blockIdx.x * CH + threadIdx.x;
+  if (threadIdx.x >= CH || c >= C) return;
   sums[c] = (float)s0;
   sums[C + c] = (float)s1;
   if (dbeta) dbeta[c] = (accf != 0.f ? accf * dbeta[c] : 0.f) + (float)s0;
@@ -308,8 +312,12 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nb
 extern "C" int mi355_bn_bwd_finalize(const float* partial, int nblocks, int C, float* sums, float* dgamma, float* dbeta,
                                      float acc, mi355_stream_t s) {
   MI355_CHECK_ARG(partial && sums, "bn_bwd_finalize: null pointer");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, (hipStream_t)s, partial, nblocks, C, sums,
-                     dgamma, dbeta, acc);
+  if (nblocks > 128)      // (see mi355_bn_finalize)
+    hipLaunchKernelGGL((bn_bwd_finalize_kernel<4, 256>), dim3(ceil_div(C, 4)), dim3(1024), 0, (hipStream_t)s, partial, nblocks, C,
+                       sums, dgamma, dbeta, acc);
+  else
+    hipLaunchKernelGGL((bn_bwd_finalize_kernel<32, 32>), dim3(ceil_div(C, 32)), dim3(1024), 0, (hipStream_t)s, partial, nblocks, C,
+                       sums, dgamma, dbeta, acc);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }

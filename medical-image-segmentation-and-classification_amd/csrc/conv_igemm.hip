@@ -505,6 +505,7 @@ static int launch_dma(const ConvArgs& a, hipStream_t s) {
 }
 
 #include "conv3x3_halo.hpp"
+#include "conv1x1_stream.hpp"
 
 template <typename T, int BN, int BK>
 static int launch(const ConvArgs& a, hipStream_t s) {
@@ -521,7 +522,7 @@ static int launch_bn(const ConvArgs& a, hipStream_t s) {
   return launch<T, 32, BK>(a, s);
 }
 
-enum IgemmVariant { IG_GENERIC = 0, IG_DMA, IG_HALO_8x32, IG_HALO_16x16 };
+enum IgemmVariant { IG_GENERIC = 0, IG_DMA, IG_HALO_8x32, IG_HALO_16x16, IG_STREAM1x1 };
 
 // ONE place that decides which kernel serves a shape (also used by the statistics-row query).
 static IgemmVariant pick_variant(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int mul, int kmul, int off,
@@ -537,6 +538,9 @@ static IgemmVariant pick_variant(int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
     if (Wo % 32 == 0 && Ho % 8 == 0) return IG_HALO_8x32;
     if (Wo % 16 == 0 && Ho % 16 == 0) return IG_HALO_16x16;
   }
+  // narrow pointwise convolutions (and their data gradients): register-resident weights, streaming pixels
+  if (KH == 1 && KW == 1 && mul == 1 && div == 1 && !up && off == 0 && Ho == Hi && Wo == Wi && stream1x1_shape(Ci, Co))
+    return IG_STREAM1x1;
   if (Co % 64 != 0 && Ci % 64 != 0) return IG_GENERIC;      // 32-wide tile with a 32-deep slab: too few DMA pieces per wave
   return IG_DMA;
 }
@@ -552,6 +556,7 @@ extern "C" int mi355_conv2d_igemm_stat_rows(int N, int Hi, int Wi, int Ci, int H
     case IG_HALO_8x32: return N * (Ho / 8) * (Wo / 32);
     case IG_HALO_16x16: return N * (Ho / 16) * (Wo / 16);
     case IG_DMA: return ceil_div((long long)N * Ho * Wo, 128);
+    case IG_STREAM1x1: return stream1x1_grid((long long)N * Ho * Wo);
     default: return 0;       // generic kernel: no fused statistics, run mi355_bn_stats
   }
 }
@@ -601,6 +606,7 @@ extern "C" int mi355_conv2d_igemm(const void* in, const void* wk, const float* b
       switch (v) {
         case IG_HALO_8x32: return launch_halo_rw<T, 8, 32>(a, st);
         case IG_HALO_16x16: return launch_halo_rw<T, 16, 16>(a, st);
+        case IG_STREAM1x1: return launch_stream1x1<T>(a, st);
         case IG_DMA:
           // measured on MI355X (AttentionUNet shapes): the 2-deep BK=64 ring (2 workgroups/CU) wins for 128-wide tiles,
           // the 3-deep BK=32 ring (3-4 workgroups/CU) for 64-wide tiles and for Ci % 64 != 0

@@ -443,7 +443,7 @@ class Builder:
                     acc = self.acc_flag(x)
                     xg = self.grad_of(x)
                     tag = self.igemm_tag(x.C, Co, k, s, 2 * x.H, 2 * x.W, True, False, M=x.N * 4 * x.H * x.W)
-                    if lib.mi355_conv2d_igemm_variant(Ho, Wo, Co, 2 * x.H, 2 * x.W, x.C, k, k, 1, -1, p, s, 0, self.code) >= 2:
+                    if lib.mi355_conv2d_igemm_variant(Ho, Wo, Co, 2 * x.H, 2 * x.W, x.C, k, k, 1, -1, p, s, 0, self.code) in (2, 3):
                         # the data gradient lives on the up-sampled grid; its 2x2 sums go straight to the half-resolution
                         # gradient in the kernel epilogue (no full-resolution temporary, no separate pass)
                         self.bwd.append(Launch("mi355_conv2d_igemm", dy, wb, None, xg, x.N, Ho, Wo, Co, dy.ld, 2 * x.H, 2 * x.W,
@@ -472,6 +472,8 @@ class Builder:
                 return "conv3x3_halo_rw_kernel<8,32>"
             if Wo % 16 == 0 and Ho % 16 == 0:
                 return "conv3x3_halo_rw_kernel<16,16>"
+        if k == 1 and s == 1 and not up and (ci, co) in ((64, 32), (32, 64), (128, 64), (64, 128), (64, 64), (32, 32)):
+            return f"conv1x1_stream_kernel<{ci},{co}>"
         k64 = ci % 64 == 0
         if bn == 128:
             return "conv_igemm_dma_kernel<128,64,2>" if k64 else "conv_igemm_dma_kernel<128,32,3>"

@@ -226,3 +226,49 @@ def test_conv_fused_bn_statistics(case, dtype):
     assert rel_err(mu.cpu(), yf.mean((0, 2, 3))) < 1e-4
     assert rel_err(isd.cpu(), 1 / torch.sqrt(yf.var((0, 2, 3), unbiased=False) + 1e-5)) < 1e-4
     assert lib.mi355_conv2d_igemm_stat_rows(n, h, w_, ci, ho, wo, co, k, k, s, 1, -p, 1, up, DTYPE_CODE[torch.float32]) == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("ci,co", [(64, 32), (32, 64), (128, 64), (64, 128), (64, 64), (32, 32)])
+@pytest.mark.parametrize("nhw", [(3, 9, 7), (2, 40, 37)])
+def test_pointwise_stream_kernel(nhw, ci, co, dtype):
+    """Narrow 1x1 convolutions run on conv1x1_stream_kernel (variant 4): ragged pixel counts, bias + ReLU + fused statistics,
+    then the same call reading / accumulating into channel slices of wider buffers (the data-gradient use)."""
+    n, h, w_ = nhw
+    code = DTYPE_CODE[dtype]
+    assert lib.mi355_conv2d_igemm_variant(h, w_, ci, h, w_, co, 1, 1, 1, 1, 0, 1, 0, code) == 4
+    g = torch.Generator().manual_seed(ci * 7 + co)
+    x = torch.randn(n, ci, h, w_, generator=g); w = torch.randn(co, ci, 1, 1, generator=g) / ci ** 0.5
+    b = torch.randn(co, generator=g)
+    ref = F.relu(F.conv2d(q(x, dtype), q(w, dtype), b))
+    rows = lib.mi355_conv2d_igemm_stat_rows(n, h, w_, ci, h, w_, co, 1, 1, 1, 1, 0, 1, 0, code)
+    assert rows == min(-(-n * h * w_ // 256), 2048)
+    part = torch.full((rows * 2 * co,), float("nan"), device=DEV)
+    y = torch.full((n, h, w_, co), float("nan"), dtype=dtype, device=DEV)
+    wf, wb = pack_w(w, dtype)
+    xd = to_nhwc(x, dtype)
+    lib.mi355_conv2d_igemm(xd, wf, b.to(DEV), y, n, h, w_, ci, ci, h, w_, co, co, 1, 1, 1, 1, 0, 1, 0, 2, part, code)
+    sc, sh, mu, isd = (torch.empty(co, device=DEV) for _ in range(4))
+    lib.mi355_bn_finalize(part, rows, n * h * w_, co, torch.ones(co, device=DEV), torch.zeros(co, device=DEV), None, None, None,
+                          0.1, 1e-5, sc, sh, mu, isd)
+    torch.cuda.synchronize()
+    yf = from_nhwc(y)
+    assert rel_err(yf, ref) < TOL[dtype]
+    assert rel_err(mu.cpu(), yf.mean((0, 2, 3))) < 1e-4
+    assert rel_err(isd.cpu(), 1 / torch.sqrt(yf.var((0, 2, 3), unbiased=False) + 1e-5)) < 1e-4
+    # data gradient of the same layer: dy [.., co] -> dx [.., ci] with the transposed pack, read from a slice of a wider
+    # buffer and ACCUMULATED into a slice of another
+    dy = torch.randn(n, co, h, w_, generator=g)
+    dref = F.conv_transpose2d(q(dy, dtype), q(w, dtype))
+    wide_in = torch.zeros(n, h, w_, co + 32, dtype=dtype, device=DEV); wide_in[..., 32:] = to_nhwc(dy, dtype)
+    base = torch.randn(n, h, w_, ci + 64, generator=g).to(dtype)
+    out = base.clone().to(DEV)
+    es = out.element_size()
+    assert lib.mi355_conv2d_igemm_variant(h, w_, co, h, w_, ci, 1, 1, 1, -1, 0, 1, 0, code) == 4
+    lib.mi355_conv2d_igemm(wide_in.data_ptr() + 32 * es, wb, None, out.data_ptr() + 32 * es, n, h, w_, co, co + 32, h, w_, ci,
+                           ci + 64, 1, 1, 1, -1, 0, 1, 0, 1, None, code)
+    torch.cuda.synchronize()
+    got = out.float().cpu()
+    exp = base.float().clone(); exp[..., 32:32 + ci] += q(dref, dtype).permute(0, 2, 3, 1)
+    assert rel_err(got[..., 32:32 + ci], q(exp[..., 32:32 + ci], dtype)) < TOL[dtype]
+    assert torch.equal(got[..., :32], base.float()[..., :32]) and torch.equal(got[..., 32 + ci:], base.float()[..., 32 + ci:])

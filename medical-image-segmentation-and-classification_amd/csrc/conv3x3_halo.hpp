@@ -112,29 +112,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_rw_kernel(const ConvArgs 
 
   // ---- fragment geometry ------------------------------------------------------------------------------------------
   const int q00 = (wm * RW) * PW + l16;              // patch pixel of (first wave row, x = l16, column shift 0)
-  int boff[NB];
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    const int row = wn * WTN + nb * 16 + l16;
-    boff[nb] = row * PIXB + ((c4 ^ (((row >> 2) & 1) << 1)) << 4);
-  }
-  // byte offset of every pixel fragment this lane ever reads inside a patch buffer: [patch column][patch row][x block]
-  // (36 registers; the main loop then issues its LDS reads without any address arithmetic in front of the MFMAs)
-  int aoff[3][RW + 2][XB];
+  // weight rows of block nb sit nb * 16 rows further on: the swizzle bit (row >> 2) & 1 does not change, so the block is an
+  // immediate offset of the LDS read
+  const int brow0 = wn * WTN + l16;
+  const int boff0 = brow0 * PIXB + ((c4 ^ (((brow0 >> 2) & 1) << 1)) << 4);
+  // byte offset of every pixel fragment this lane ever reads inside a patch buffer: [patch column][patch row] (18 registers;
+  // the x block is an immediate + xb * 16 * PIXB for the same reason), so the main loop issues its LDS reads without any
+  // address arithmetic in front of the MFMAs
+  int aoff[3][RW + 2];
 #pragma unroll
   for (int pw = 0; pw < 3; ++pw)
 #pragma unroll
-    for (int pr = 0; pr < RW + 2; ++pr)
-#pragma unroll
-      for (int xb = 0; xb < XB; ++xb) {
-        const int q = q00 + pr * PW + xb * 16 + pw;
-        aoff[pw][pr][xb] = q * PIXB + ((c4 ^ (((q >> 2) & 1) << 1)) << 4);
-      }
-  f32x4 acc[MB][NB];
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int pr = 0; pr < RW + 2; ++pr) {
+      const int q = q00 + pr * PW + pw;
+      aoff[pw][pr] = q * PIXB + ((c4 ^ (((q >> 2) & 1) << 1)) << 4);
+    }
+  f32x4 acc[MB][NB];      // first written by the very first step (an MFMA with a zero C operand: no 64 v_mov to clear them)
 
   const int nC = a.Ci / BK;
   // prologue: patch of chunk 0 and the stages of steps 0 and 1 (stage index == patch column: three steps per chunk)
@@ -150,8 +143,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_rw_kernel(const ConvArgs 
   // One step = patch column pw of chunk `chunk` (48 MFMAs per wave).  Every DMA instruction of the step — the stage two steps
   // ahead, and in column 0 the next chunk's patch — is issued from INSIDE the MFMA stream, a piece after each patch row's
   // MFMAs, so that its address arithmetic and m0 traffic run in the shadow of the matrix pipe instead of in front of it.
-  auto step = [&](int chunk, auto pw_tag, auto par_tag) {
+  auto step = [&](int chunk, auto pw_tag, auto par_tag, auto first_tag) {
     constexpr int pw = decltype(pw_tag)::value;
+    constexpr bool FIRST = decltype(first_tag)::value;      // step (chunk 0, column 0): the ph == 0 MFMA of a block is its first
     constexpr int par = decltype(par_tag)::value;      // chunk & 1: the patch buffer is a compile-time LDS offset
     constexpr int NPIECE = B_IT + (pw == 0 ? P_IT : 0);
     constexpr int NPR = RW + 2;
@@ -166,12 +160,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_rw_kernel(const ConvArgs 
 #pragma unroll
     for (int ph = 0; ph < 3; ++ph)
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) bfr[ph][nb] = *reinterpret_cast<const bf16x8*>(pb + ph * SLAB + boff[nb]);
+      for (int nb = 0; nb < NB; ++nb) bfr[ph][nb] = *reinterpret_cast<const bf16x8*>(pb + ph * SLAB + nb * 16 * PIXB + boff0);
     bf16x8 afr[NPR][XB];
 #pragma unroll
     for (int pr = 0; pr < NPR; ++pr)
 #pragma unroll
-      for (int xb = 0; xb < XB; ++xb) afr[pr][xb] = *reinterpret_cast<const bf16x8*>(pa + aoff[pw][pr][xb]);
+      for (int xb = 0; xb < XB; ++xb) afr[pr][xb] = *reinterpret_cast<const bf16x8*>(pa + xb * 16 * PIXB + aoff[pw][pr]);
     __builtin_amdgcn_sched_barrier(0);              // every fragment read of the step is in flight before the first MFMA
 #pragma unroll
     for (int pr = 0; pr < NPR; ++pr) {
@@ -183,7 +177,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_rw_kernel(const ConvArgs 
           if (orow >= 0 && orow < RW) {
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
-              acc[orow * XB + xb][nb] = mfma_16x16x32<T>(bfr[ph][nb], afr[pr][xb], acc[orow * XB + xb][nb]);      // D[channel][pixel]
+              acc[orow * XB + xb][nb] = mfma_16x16x32<T>(bfr[ph][nb], afr[pr][xb],      // D[channel][pixel]
+                                                         (FIRST && ph == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[orow * XB + xb][nb]);
           }
         }
 #pragma unroll
@@ -201,15 +196,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_rw_kernel(const ConvArgs 
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>;
-  for (int chunk = 0; chunk < nC; chunk += 2) {
-    step(chunk, I0{}, I0{});
-    step(chunk, I1{}, I0{});
-    step(chunk, I2{}, I0{});
-    if (chunk + 1 < nC) {
-      step(chunk + 1, I0{}, I1{});
-      step(chunk + 1, I1{}, I1{});
-      step(chunk + 1, I2{}, I1{});
-    }
+  using No = std::false_type;
+  step(0, I0{}, I0{}, std::true_type{});
+  for (int chunk = 0;; chunk += 2) {                   // (the loop body starts at column 1 so that only ONE extra step body exists)
+    step(chunk, I1{}, I0{}, No{});
+    step(chunk, I2{}, I0{}, No{});
+    if (chunk + 1 >= nC) break;
+    step(chunk + 1, I0{}, I1{}, No{});
+    step(chunk + 1, I1{}, I1{}, No{});
+    step(chunk + 1, I2{}, I1{}, No{});
+    if (chunk + 2 >= nC) break;
+    step(chunk + 2, I0{}, I0{}, No{});
   }
   wait_vmcnt<0>();                                   // (the zero-fill pieces of the last two steps)
 

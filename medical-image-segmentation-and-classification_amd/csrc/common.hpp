@@ -87,6 +87,21 @@ template <> __device__ __forceinline__ f32x4 mfma_16x16x32<f16_t>(bf16x8 a, bf16
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), result in every lane: quad_perm [1,0,3,2], [2,3,0,1], then
+// row_half_mirror and row_mirror (after the quad steps every lane of a quad holds the quad sum, so mirroring pairs distinct
+// quads / halves).  Four VALU adds with a DPP source, no LDS traffic (__shfl_xor compiles to ds_bpermute_b32).
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v = dpp_add<0xB1>(v);
+  v = dpp_add<0x4E>(v);
+  v = dpp_add<0x141>(v);
+  return dpp_add<0x140>(v);
+}
+
 template <typename T> __device__ __forceinline__ Vec16<T> ld16(const T* p) {
   Vec16<T> r;
   *reinterpret_cast<uint4*>(&r) = *reinterpret_cast<const uint4*>(p);

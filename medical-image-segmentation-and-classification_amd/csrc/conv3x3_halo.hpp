@@ -127,7 +127,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_rw_kernel(const ConvArgs 
       const int q = q00 + pr * PW + pw;
       aoff[pw][pr] = q * PIXB + ((c4 ^ (((q >> 2) & 1) << 1)) << 4);
     }
-  f32x4 acc[MB][NB];      // first written by the very first step (an MFMA with a zero C operand: no 64 v_mov to clear them)
+  // first written by the very first step, whose MFMAs take the BIAS as their C operand: no 64 v_mov to clear the accumulators
+  // and no 64 v_add in the epilogue (a lane's four values of a block are channels 4*c4 .. +3 of block nb)
+  f32x4 acc[MB][NB];
+  f32x4 bias4[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+    bias4[nb] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n0 + wn * WTN + nb * 16 + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nC = a.Ci / BK;
   // prologue: patch of chunk 0 and the stages of steps 0 and 1 (stage index == patch column: three steps per chunk)
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_rw_kernel(const ConvArgs 
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
               acc[orow * XB + xb][nb] = mfma_16x16x32<T>(bfr[ph][nb], afr[pr][xb],      // D[channel][pixel]
-                                                         (FIRST && ph == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[orow * XB + xb][nb]);
+                                                         (FIRST && ph == 0) ? bias4[nb] : acc[orow * XB + xb][nb]);
           }
         }
 #pragma unroll
@@ -216,50 +222,55 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_rw_kernel(const ConvArgs 
   // 8-byte LDS write per lane (conflict-free at the 144-B row pitch), and the tile leaves as 16-byte row-contiguous stores
   // (whole 128-B lines; 8-byte stores straight from the registers were measured: 4x the line accesses, -10 %).
   T* __restrict__ out = reinterpret_cast<T*>(a.out);
-  const float lo = a.relu ? 0.f : -INFINITY;
   struct alignas(8) Pack4 { T v[4]; };
-  float bch[NB][4];
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bch[nb][r] = a.bias ? a.bias[n0 + wn * WTN + nb * 16 + 4 * c4 + r] : 0.f;
-  float sm[NB][4], sq[NB][4];
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { sm[nb][r] = 0.f; sq[nb][r] = 0.f; }
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
-    const int row = wm * WTM + mb * 16 + l16;                // tile pixel of this lane in block mb
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      Pack4 pk;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        pk.v[r] = from_f32<T>(fmaxf(acc[mb][nb][r] + bch[nb][r], lo));
-        if (a.stats) {                                        // statistics of the ROUNDED outputs
-          const float v = to_f32<T>(pk.v[r]);
-          sm[nb][r] += v;
-          sq[nb][r] += v * v;
-        }
-      }
-      *reinterpret_cast<Pack4*>(lds + row * C_PITCH + (wn * WTN + nb * 16 + 4 * c4) * 2) = pk;
-    }
-  }
   float* const red = reinterpret_cast<float*>(lds + Cfg::C_BYTES);      // [WM][2][BN] behind the C tile
-  if (a.stats) {        // fold the 16 pixel lanes of every channel, then the two wave rows through LDS
+  // ReLU and the statistics are workgroup-uniform switches: four straight-line variants instead of 64 dead v_max / a test per
+  // block.  Statistics are of the ROUNDED outputs, summed two channels at a time (packed fp32 adds / fmas), folded over
+  // the 16 pixel lanes of a row with DPP adds (no LDS traffic), then over the two wave rows through LDS.
+  auto finish = [&](auto relu_tag, auto stats_tag) {
+    constexpr bool RELU = decltype(relu_tag)::value, STATS = decltype(stats_tag)::value;
+    f32x2 sm[NB][2], sq[NB][2];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float s1 = sm[nb][r], s2 = sq[nb][r];
+      for (int j = 0; j < 2; ++j) { sm[nb][j] = f32x2{0.f, 0.f}; sq[nb][j] = f32x2{0.f, 0.f}; }
 #pragma unroll
-        for (int m = 1; m < 16; m <<= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
-        if (l16 == 0) {
-          red[(wm * 2 + 0) * BN + wn * WTN + nb * 16 + 4 * c4 + r] = s1;
-          red[(wm * 2 + 1) * BN + wn * WTN + nb * 16 + 4 * c4 + r] = s2;
+    for (int mb = 0; mb < MB; ++mb) {
+      const int row = wm * WTM + mb * 16 + l16;                // tile pixel of this lane in block mb
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        Pack4 pk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pk.v[r] = from_f32<T>(RELU ? __builtin_amdgcn_fmed3f(acc[mb][nb][r], 0.f, INFINITY) : acc[mb][nb][r]);
+        if constexpr (STATS) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const f32x2 v = {to_f32<T>(pk.v[2 * j]), to_f32<T>(pk.v[2 * j + 1])};
+            sm[nb][j] += v;
+            sq[nb][j] += v * v;
+          }
         }
+        *reinterpret_cast<Pack4*>(lds + row * C_PITCH + (wn * WTN + nb * 16 + 4 * c4) * 2) = pk;
       }
+    }
+    if constexpr (STATS) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float s1 = row16_sum(sm[nb][r >> 1][r & 1]), s2 = row16_sum(sq[nb][r >> 1][r & 1]);
+          if (l16 == 0) {
+            red[(wm * 2 + 0) * BN + wn * WTN + nb * 16 + 4 * c4 + r] = s1;
+            red[(wm * 2 + 1) * BN + wn * WTN + nb * 16 + 4 * c4 + r] = s2;
+          }
+        }
+    }
+  };
+  using Yes = std::true_type;
+  if (a.stats) {
+    if (a.relu) finish(Yes{}, Yes{}); else finish(No{}, Yes{});
+  } else {
+    if (a.relu) finish(Yes{}, No{}); else finish(No{}, No{});
   }
   __syncthreads();
   if (a.stats && tid < 2 * BN) {

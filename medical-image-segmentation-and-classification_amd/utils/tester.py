@@ -2,12 +2,19 @@
 reference's utils/tester.py (segmentation metrics :92-193, classification metrics :49-88, eval
 loops :197-312).  Per-sample counters come from one HIP reduction per batch instead of ~9 host
 syncs per sample."""
+import os
+
 import numpy as np
 import torch
 
 from mi355.lib import lib
 
 CLASSES = ["COVID", "Healthy", "Non-COVID"]
+DATA_ROOT = "dataset"
+WEIGHTS_ROOT = "weights"
+CLS_WEIGHTS_DIR = os.path.join(WEIGHTS_ROOT, "classification_models")
+SEG_WEIGHTS_DIR = os.path.join(WEIGHTS_ROOT, "segmentation_models")
+IMG_SIZE = 256
 _E = 1e-7
 
 
@@ -123,3 +130,134 @@ def test_segmentation_model(model, test_loader, device, model_name):
     print(f"IoU (Jaccard):     {avg['iou']:.2f}%\nDice Coefficient:  {avg['dice']:.2f}%\nPixel Accuracy:    {avg['pixel_accuracy']:.2f}%")
     print(f"Precision:         {avg['precision']:.2f}%\nRecall:            {avg['recall']:.2f}%\nF1 Score:          {avg['f1']:.2f}%\n{'=' * 60}\n")
     return avg
+
+
+# ---- the whole-zoo driver and its reports (tester.py:513-876) -------------------------------------------------------
+_CLS_FILES = {"ResNet18": "ResNet18_best_acc.pt", "ResNet50": "ResNet50_best_acc.pt", "VGG16": "VGG16_best_acc.pt",
+              "VGG19": "VGG19_best_acc.pt", "CLIP": "CLIP_best_acc.pt"}
+_SEG_FILES = {"ResNetUnet": "ResNetUnet_best_loss.pt", "AttentionUNet": "AttentionUNet_best_loss.pt",
+              "R2Unet": "R2Unet_best_loss.pt", "R2AttUnet": "R2AttUnet_best_loss.pt", "CLIPSeg": "CLIPSeg_best_loss.pt"}
+
+
+def test_all_models(device="cuda", batch_size=16, cls_loader=None, seg_loader=None, cls_weights_dir=None,
+                    seg_weights_dir=None):
+    """Evaluate every checkpoint found under the weights directories (tester.py:513-735): same model names, file
+    names, skip rules and result dictionary.  The reference builds its test loaders from `dataset/` with
+    Albumentations (:531-555, :569-580, :651-666), which is the data plane, not this path: the loaders are
+    arguments here (`seg_loader` is expected to carry batch_size // 2 like the reference's, :663), and a missing one
+    takes the reference's "dataset not found" branch (:637-639, :729-731).  The CLIP / CLIPSeg entries (hub models,
+    out of scope: SURVEY.md section 8) are reported and skipped.  Checkpoints are the reference's own format: a plain
+    `state_dict` saved by `train` (helpers.py:394-400)."""
+    from utils.helpers import get_class_model, get_seg_model
+    if not torch.cuda.is_available():
+        raise RuntimeError("test_all_models: the MI355X path needs a GPU (the reference falls back to the CPU, tester.py:524)")
+    device = torch.device(device)
+    print(f"[INFO] Using device: {device}")
+    cls_weights_dir = CLS_WEIGHTS_DIR if cls_weights_dir is None else cls_weights_dir
+    seg_weights_dir = SEG_WEIGHTS_DIR if seg_weights_dir is None else seg_weights_dir
+    results = {}
+
+    def run(files, wdir, loader, build, test, n_samples_label):
+        print(f"\n[INFO] {n_samples_label} Test Dataset: {len(loader.dataset)} samples")
+        for model_name, weight_file in files.items():
+            weight_path = os.path.join(wdir, weight_file)
+            if not os.path.exists(weight_path):
+                print(f"\n[WARNING] Weights not found for {model_name}: {weight_path}")
+                print(f"Skipping {model_name}...")
+                continue
+            if model_name in ("CLIP", "CLIPSeg"):
+                print(f"\n[WARNING] {model_name} is a hub model outside the MI355X conv path; skipping {weight_path}")
+                continue
+            try:
+                model = build(model_name)
+                model.load_state_dict(torch.load(weight_path, map_location=device))
+                model = model.to(device)
+                results[model_name] = test(model, loader, device, model_name)
+                del model
+                torch.cuda.empty_cache()
+            except Exception as e:      # (the reference reports and moves on to the next model, :630-635)
+                print(f"\n[ERROR] Failed to test {model_name}: {e}")
+                import traceback
+                traceback.print_exc()
+                continue
+
+    if cls_loader is None:
+        print(f"\n[WARNING] Classification test dataset not found: no loader given for {DATA_ROOT!r}")
+        print("Skipping classification model testing...")
+    else:
+        run(_CLS_FILES, cls_weights_dir, cls_loader, lambda n: get_class_model(n)[0], test_classification_model, "Classification")
+    if seg_loader is None:
+        print(f"\n[WARNING] Segmentation test dataset not found: no loader given for {DATA_ROOT!r}")
+        print("Skipping segmentation model testing...")
+    elif len(seg_loader.dataset) == 0:
+        print("\n[WARNING] Segmentation test dataset is empty. Skipping segmentation testing.")
+    else:
+        run(_SEG_FILES, seg_weights_dir, seg_loader, get_seg_model, test_segmentation_model, "Segmentation")
+    return results
+
+
+def print_summary(results):
+    """The two result tables and the best model of each family (tester.py:738-805), same text."""
+    if not results:
+        print("\n[INFO] No test results to display.")
+        return
+    print("\n" + "=" * 80)
+    print(" " * 25 + "TEST RESULTS SUMMARY")
+    print("=" * 80)
+    cls_models = [m for m in ["ResNet18", "ResNet50", "VGG16", "VGG19", "CLIP"] if m in results]
+    if cls_models:
+        print("\nCLASSIFICATION MODELS:")
+        print("-" * 80)
+        print(f"{'Model':<20} {'Accuracy':<12} {'Precision':<12} {'Recall':<12} {'F1 Score':<12}")
+        print("-" * 80)
+        for model in cls_models:
+            m = results[model]
+            print(f"{model:<20} {m['accuracy']:>10.2f}% {m['precision']:>10.2f}% {m['recall']:>10.2f}% {m['f1']:>10.2f}%")
+        best = max(cls_models, key=lambda x: results[x]["accuracy"])
+        print(f"\n\U0001F3C6 Best Classification Model: {best} (Accuracy: {results[best]['accuracy']:.2f}%)")
+    seg_models = [m for m in ["ResNetUnet", "AttentionUNet", "R2Unet", "R2AttUnet", "CLIPSeg"] if m in results]
+    if seg_models:
+        print("\n\nSEGMENTATION MODELS:")
+        print("-" * 80)
+        print(f"{'Model':<20} {'IoU':<10} {'Dice':<10} {'Precision':<12} {'Recall':<12} {'F1 Score':<12}")
+        print("-" * 80)
+        for model in seg_models:
+            m = results[model]
+            print(f"{model:<20} {m['iou']:>8.2f}% {m['dice']:>8.2f}% {m['precision']:>10.2f}% {m['recall']:>10.2f}% {m['f1']:>10.2f}%")
+        best = max(seg_models, key=lambda x: results[x]["dice"])
+        print(f"\n\U0001F3C6 Best Segmentation Model: {best} (Dice: {results[best]['dice']:.2f}%)")
+    print("=" * 80 + "\n")
+
+
+def save_results_to_csv(results, cls_output_path="results/classification_test_results.csv",
+                        seg_output_path="results/segmentation_test_results.csv"):
+    """One CSV per family, a `Model` column followed by the scalar metrics in dictionary order (tester.py:808-876;
+    written through pandas like the reference, so the float formatting is identical)."""
+    if not results:
+        print("\n[INFO] No results to save.")
+        return
+    import pandas as pd
+    cls_models = [k for k in results.keys() if any(x in k for x in ["ResNet18", "ResNet50", "VGG", "CLIP"]) and "Seg" not in k]
+    seg_models = [k for k in results.keys() if "Unet" in k or "UNet" in k or "CLIPSeg" in k]
+    if cls_models:
+        rows = []
+        for name in cls_models:
+            row = {"Model": name}
+            row.update(results[name])
+            for k in ("confusion_matrix", "precision_per_class", "recall_per_class", "f1_per_class"):
+                row.pop(k, None)
+            rows.append(row)
+        pd.DataFrame(rows).to_csv(cls_output_path, index=False)
+        print(f"\n[INFO] Classification results saved to: {cls_output_path}")
+    else:
+        print("\n[INFO] No classification results to save.")
+    if seg_models:
+        rows = []
+        for name in seg_models:
+            row = {"Model": name}
+            row.update(results[name])
+            rows.append(row)
+        pd.DataFrame(rows).to_csv(seg_output_path, index=False)
+        print(f"[INFO] Segmentation results saved to: {seg_output_path}")
+    else:
+        print("\n[INFO] No segmentation results to save.")

@@ -310,6 +310,41 @@ def test_tester_functions_match_oracle_metrics(capsys):
     assert abs(cm["accuracy"] - 100 * 5 / 7) < 1e-9 and cm["confusion_matrix"].sum() == 7
 
 
+def test_test_all_models_walks_the_weight_directories(tmp_path, capsys):
+    """utils.tester.test_all_models (tester.py:513-735): evaluates the checkpoints that exist under the reference's file
+    names, skips the missing ones with the reference's warning, takes the dataset-not-found branch without a loader, and
+    returns the same dictionary the per-model loops return; print_summary / save_results_to_csv accept it."""
+    from torch.utils.data import DataLoader, TensorDataset
+    from utils import tester
+    from utils.helpers import get_class_model, get_seg_model
+    seg_dir, cls_dir = tmp_path / "seg", tmp_path / "cls"
+    seg_dir.mkdir(); cls_dir.mkdir()
+    torch.manual_seed(11)
+    seg = get_seg_model("AttentionUNet")
+    torch.save(seg.state_dict(), seg_dir / "AttentionUNet_best_loss.pt")
+    cls, _ = get_class_model("ResNet18")
+    torch.save(cls.state_dict(), cls_dir / "ResNet18_best_acc.pt")
+    (cls_dir / "CLIP_best_acc.pt").write_bytes(b"")
+    xs, ms = zip(*[otrain.synthetic_batch(2, 32, seed=s) for s in (1, 2)])
+    seg_dl = DataLoader(TensorDataset(torch.cat(xs), torch.cat(ms)), batch_size=2)
+    cls_dl = DataLoader(TensorDataset(torch.cat(xs), torch.tensor([0, 1, 2, 1])), batch_size=4)
+    res = tester.test_all_models("cuda", 4, cls_loader=cls_dl, seg_loader=seg_dl, cls_weights_dir=str(cls_dir),
+                                 seg_weights_dir=str(seg_dir))
+    out = capsys.readouterr().out
+    assert set(res) == {"ResNet18", "AttentionUNet"}
+    assert "Weights not found for VGG16" in out and "Weights not found for R2Unet" in out and "CLIP is a hub model" in out
+    direct = tester.test_segmentation_model(seg.to(DEV), seg_dl, torch.device(DEV), "AttentionUNet")
+    assert all(abs(direct[k] - res["AttentionUNet"][k]) < 1e-9 for k in direct)
+    assert res["ResNet18"]["confusion_matrix"].sum() == 4
+    none = tester.test_all_models("cuda", 4, cls_weights_dir=str(cls_dir), seg_weights_dir=str(seg_dir))
+    out = capsys.readouterr().out
+    assert none == {} and "Classification test dataset not found" in out and "Segmentation test dataset not found" in out
+    tester.print_summary(res)
+    tester.save_results_to_csv(res, str(tmp_path / "c.csv"), str(tmp_path / "s.csv"))
+    assert (tmp_path / "c.csv").read_text().startswith("Model,accuracy,precision,recall,f1\nResNet18,")
+    assert (tmp_path / "s.csv").read_text().startswith("Model,iou,dice,pixel_accuracy,precision,recall,f1\nAttentionUNet,")
+
+
 def _pool_gap(sd64, x):
     """smallest relative gap between the two largest values of a 2x2 max-pool window (positive maximum) anywhere in
     the VGG16_BN feature stack, evaluated in fp64"""

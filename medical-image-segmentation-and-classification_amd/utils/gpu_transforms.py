@@ -61,11 +61,8 @@ class SegBatchTransform:
             bcs.append([1 + self._u(-0.1, 0.1), self._u(-0.1, 0.1)] if self._u(0, 1) < 0.5 else [1.0, 0.0])
         return mats, bcs
 
-    @torch.no_grad()
-    def __call__(self, images, masks=None, params=None):
-        images = images.to(self.device).contiguous()
-        n, hs, ws, c = images.shape
-        assert images.dtype == torch.uint8 and c == 3
+    def _to_square(self, images, masks, n, hs, ws):
+        """A.Resize(size, size) (trainer.py:85-87): aspect ratio not kept."""
         s = self.size
         m0 = torch.tensor([resize_matrix(hs, ws, s, s)] * n, dtype=torch.float32, device=self.device)
         img = torch.empty(n, s, s, 3, dtype=torch.uint8, device=self.device)
@@ -75,6 +72,15 @@ class SegBatchTransform:
             masks = masks.to(self.device).contiguous().view(n, hs, ws, 1)
             msk = torch.empty(n, s, s, 1, dtype=torch.uint8, device=self.device)
             lib.mi355_warp_u8(masks, n, hs, ws, 1, m0, msk, s, s, 1, 0)
+        return img, msk
+
+    @torch.no_grad()
+    def __call__(self, images, masks=None, params=None):
+        images = images.to(self.device).contiguous()
+        n, hs, ws, c = images.shape
+        assert images.dtype == torch.uint8 and c == 3
+        s = self.size
+        img, msk = self._to_square(images, masks, n, hs, ws)
         bc = None
         if self.train:
             mats, bcs = params if params is not None else self.draw(n)
@@ -94,3 +100,36 @@ class SegBatchTransform:
         y = torch.empty(n, 1, s, s, dtype=torch.float32, device=self.device)
         lib.mi355_normalize_u8(msk, n, s, s, 1, None, None, None, y)
         return x, y
+
+
+def _py3round(v):
+    """Albumentations' rounding of the resized extent (round half to even)."""
+    return int(round(v))
+
+
+def longest_max_size_shape(hs, ws, size):
+    sc = size / max(hs, ws)
+    return _py3round(hs * sc), _py3round(ws * sc)
+
+
+class ClsBatchTransform(SegBatchTransform):
+    """train_cls_transform / val_cls_transform (trainer.py:52-82) for a batch of equally sized images:
+    ``A.LongestMaxSize(size)`` (aspect ratio kept, bilinear) -> ``A.PadIfNeeded(size, size, BORDER_CONSTANT, 0)`` (centred:
+    the odd pixel goes to the bottom / right) -> the same augmentation / normalisation tail as the segmentation pipeline.
+    ``images uint8 [N,Hs,Ws,3] -> x float32 [N,3,S,S]``."""
+
+    def _to_square(self, images, masks, n, hs, ws):
+        assert masks is None, "classification samples carry no mask"
+        s = self.size
+        h1, w1 = longest_max_size_shape(hs, ws, s)
+        m0 = torch.tensor([resize_matrix(hs, ws, h1, w1)] * n, dtype=torch.float32, device=self.device)
+        if (h1, w1) == (s, s):
+            img = torch.empty(n, s, s, 3, dtype=torch.uint8, device=self.device)
+            lib.mi355_warp_u8(images, n, hs, ws, 3, m0, img, s, s, 0, 0)
+            return img, None
+        small = torch.empty(n, h1, w1, 3, dtype=torch.uint8, device=self.device)
+        lib.mi355_warp_u8(images, n, hs, ws, 3, m0, small, h1, w1, 0, 0)
+        img = torch.zeros(n, s, s, 3, dtype=torch.uint8, device=self.device)
+        top, left = (s - h1) // 2, (s - w1) // 2
+        img[:, top:top + h1, left:left + w1] = small
+        return img, None

@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE — numpy restatement of the reference's per-sample input transforms
-(utils/trainer.py:52-115: A.Resize / A.ShiftScaleRotate / A.HorizontalFlip / A.RandomBrightnessContrast / A.Normalize /
+(utils/trainer.py:52-115: A.LongestMaxSize / A.PadIfNeeded / A.Resize / A.ShiftScaleRotate / A.HorizontalFlip / A.RandomBrightnessContrast / A.Normalize /
 ToTensorV2; utils/dataset.py:100-134: masks as float / 255).
 
 Albumentations and OpenCV are absent from the build container, so the arithmetic below follows their published
@@ -91,3 +91,29 @@ def train_seg_sample(img, mask, angle, scale, dx, dy, hflip, alpha, beta, size=2
     m1 = shift_scale_rotate_matrix(size, size, angle, scale, dx, dy, hflip)
     i2, k2 = warp_u8(i1, m1, size, size, reflect=True), warp_u8(k1, m1, size, size, nearest=True, reflect=True)
     return normalize_u8(i2, alpha, beta), normalize_u8(k2, mean=None)
+
+
+def longest_max_size_pad(img, size=256):
+    """A.LongestMaxSize(size) then A.PadIfNeeded(size, size, border_mode=BORDER_CONSTANT, value=0) (trainer.py:54-60):
+    the longer side becomes `size` (bilinear, aspect ratio kept, extents rounded half-to-even), the shorter one is padded
+    with zeros, centred, the odd pixel on the bottom / right."""
+    hs, ws, c = img.shape
+    sc = size / max(hs, ws)
+    h1, w1 = int(round(hs * sc)), int(round(ws * sc))
+    small = warp_u8(img, resize_matrix(hs, ws, h1, w1), h1, w1)
+    out = np.zeros((size, size, c), np.uint8)
+    top, left = (size - h1) // 2, (size - w1) // 2
+    out[top:top + h1, left:left + w1] = small
+    return out
+
+
+def val_cls_sample(img, size=256):
+    """val_cls_transform (trainer.py:70-82)."""
+    return normalize_u8(longest_max_size_pad(img, size))
+
+
+def train_cls_sample(img, angle, scale, dx, dy, hflip, alpha, beta, size=256):
+    """train_cls_transform (trainer.py:52-68) with its random draws given explicitly."""
+    i1 = longest_max_size_pad(img, size)
+    m1 = shift_scale_rotate_matrix(size, size, angle, scale, dx, dy, hflip)
+    return normalize_u8(warp_u8(i1, m1, size, size, reflect=True), alpha, beta)

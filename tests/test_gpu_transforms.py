@@ -61,3 +61,24 @@ def test_train_transform_matches_oracle():
     x2, y2 = SegBatchTransform(256, train=True, seed=9, device=DEV)(torch.from_numpy(imgs), torch.from_numpy(masks))
     assert torch.equal(x1, x2) and torch.equal(y1, y2) and set(np.unique(y1.cpu().numpy())) <= {0.0, 1.0}
     assert tuple(x1.shape) == (4, 3, 256, 256) and tuple(y1.shape) == (4, 1, 256, 256)
+
+
+@pytest.mark.parametrize("src", [(299, 299), (180, 333), (400, 250), (256, 256), (101, 77)])
+def test_cls_transforms_match_oracle(src):
+    """ClsBatchTransform: LongestMaxSize + zero PadIfNeeded (trainer.py:52-82) in front of the shared augmentation tail."""
+    from utils.gpu_transforms import ClsBatchTransform, shift_scale_rotate_matrix
+    imgs, _ = _batch(3, src[0], src[1], 7)
+    x = ClsBatchTransform(256, train=False, device=DEV)(torch.from_numpy(imgs))
+    assert tuple(x.shape) == (3, 3, 256, 256)
+    for i in range(3):
+        _close(x[i].cpu().numpy(), ot.val_cls_sample(imgs[i], 256))
+    draws = [(10.0, 1.03, 0.02, -0.04, True, 1.05, -0.03), (-14.0, 0.96, -0.05, 0.05, False, 0.92, 0.08), (0.0, 1.0, 0.0, 0.0, False, 1.0, 0.0)]
+    mats = [shift_scale_rotate_matrix(256, 256, a, s, dx, dy, f) for a, s, dx, dy, f, _, _ in draws]
+    x = ClsBatchTransform(256, train=True, seed=1, device=DEV)(torch.from_numpy(imgs), params=(mats, [[al, be] for *_, al, be in draws]))
+    for i, d in enumerate(draws):
+        _close(x[i].cpu().numpy(), ot.train_cls_sample(imgs[i], *d, 256), tol_levels=2)
+    if src[0] != src[1]:        # the padded band is exactly normalised black in the un-augmented output
+        v = ClsBatchTransform(256, train=False, device=DEV)(torch.from_numpy(imgs))[0].cpu().numpy()
+        black = (0 - ot.IMAGENET_MEAN) / ot.IMAGENET_STD
+        edge = v[:, 0, :] if src[0] < src[1] else v[:, :, 0]
+        assert np.allclose(edge, black[:, None], atol=1e-6)

@@ -10,10 +10,14 @@ dgrad/wgrad launches.  The 1/world averaging is folded into the clip/AdamW launc
 (plain DDP semantics; the single-device reference defines nothing else)."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
 from . import graph
+
+_NO_COMM = os.environ.get("MI355_DP_NOCOMM") == "1"
 
 
 class DataParallel:
@@ -58,6 +62,8 @@ class DataParallel:
         return buckets
 
     def _allreduce(self, lo, hi):
+        if _NO_COMM:        # probe: the cost of the bucket schedule itself (MI355_DP_NOCOMM=1), never set in production
+            return
         dist.all_reduce(self.engine.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
 
     def _run_backward(self, plan, stream):

@@ -137,6 +137,47 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args 
             acc[kh * 3 + kw][ao][bi] = mfma_16x16x32<T>(kh == 0 ? dp[ao] : (kh == 1 ? dc[ao] : dm[ao]), xk[bi], acc[kh * 3 + kw][ao][bi]);
     };
     auto wrap = [](int v, int n) { return v >= n ? v - n : v; };
+    // The rows the main loop fetches are CONSECUTIVE (ya + 2, ya + 3, ...): their per-lane source pointers advance by a row
+    // stride instead of being rebuilt from (n, r, x) with 64-bit multiplies each time, and the lane part of the bounds test
+    // (channel / image-column range) is taken once per item; only the row part, wave-uniform, is evaluated per row.
+    const int px_d = 8 * wave + lpx;
+    const int c_d = co0 + 8 * (slot ^ swz(px_d));
+    const bool lane_ok_d = c_d < a.Co;
+    const int off_d = ((x0 + px_d) * a.ldy + c_d) * (int)sizeof(T);            // per-lane byte offset inside a dY row (32 bit)
+    const char* drow_next = reinterpret_cast<const char*>(dy + (size_t)(n * a.H + ya + 2) * a.W * a.ldy);      // wave-uniform
+    const size_t d_stride = (size_t)a.W * a.ldy * sizeof(T);
+    int off_x[2];
+    bool lane_ok_x[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int piece = k == 0 ? wave : 4;
+      const int px = 8 * piece + lpx;
+      const int xx = x0 - 4 + px;
+      const int c = ci0 + 8 * (slot ^ swz(px));
+      lane_ok_x[k] = (k == 0 || wave == 0) && (unsigned)xx < (unsigned)a.W && c < a.Ci;
+      off_x[k] = ((xx >> a.up) * a.ldx + c) * (int)sizeof(T);
+    }
+    const char* xrow_next = reinterpret_cast<const char*>(x + (size_t)(n * a.Hi + ((ya + 2) >> a.up)) * a.Wi * a.ldx);
+    const size_t x_stride = (size_t)a.Wi * a.ldx * sizeof(T);
+    int r_next = ya + 2;
+    auto issue_next = [&](int xs, int ds) {          // row r_next into ring slots xs / ds, then advance
+      {
+        const bool ok = lane_ok_d && r_next >= ya && r_next < yb;
+        const char* p = ok ? drow_next + off_d : zero + slot * 16;
+        dma16(p, lds_addr(dr + ds * DROW + wave * 1024));
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int piece = k == 0 ? wave : 4;
+        const bool real = k == 0 || wave == 0;
+        const bool ok = lane_ok_x[k] && (unsigned)r_next < (unsigned)a.H;
+        const char* p = ok ? xrow_next + off_x[k] : zero + slot * 16;
+        dma16(p, lds_addr(real ? xr + xs * XROW + piece * 1024 : dump + wave * 1024));
+      }
+      drow_next += d_stride;
+      if (!a.up || (r_next & 1)) xrow_next += x_stride;      // the source row of an up-sampled input advances every second row
+      ++r_next;
+    };
 
     // ring slots: X row q -> (q - (ya-1)) mod NRX, dY row q -> (q - (ya-1)) mod NRD
     issue_row(ya - 1, 0, 0);
@@ -159,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args 
       __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
       // row r+3 is fetched from inside the MFMA stream (its address arithmetic runs in the matrix pipe's shadow), always:
       // past the band it brings zeros / unused rows into ring slots that are dead by then, which keeps vmcnt uniform
-      issue_row(r + 3, (xs + 3) & (NRX - 1), wrap(d + 3, NRD));
+      issue_next((xs + 3) & (NRX - 1), wrap(d + 3, NRD));      // row r + 3
       load_x(xs, 2, xa);
       mfma12(1, xb);
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);

@@ -10,6 +10,7 @@
 // ahead); fragments are fetched with the hardware transpose read ds_read_b64_tr_b16 from [pixel][64 ch] row images.
 // (nearest x2 up-sampling of X is folded into the row gather.)
 #pragma once
+#include <type_traits>
 #include "common.hpp"
 
 struct Wgrad3Args {
@@ -42,7 +43,7 @@ template <typename T>
 __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args a) {
   static_assert(sizeof(T) == 2, "bf16 / fp16 only");
   constexpr int XPX = 40, XROW = XPX * 128, DROW = 32 * 128;
-  constexpr int NRX = 4, NRD = 5;
+  constexpr int NRX = 4, NRD = 4;      // equal ring depths: X row q and dY row q share the slot index (q - (ya-1)) & 3
   constexpr int X_BYTES = NRX * XROW, D_BYTES = NRD * DROW;
   constexpr int ZERO_IMG = X_BYTES + D_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char lds[X_BYTES + D_BYTES + 4096];
@@ -187,21 +188,22 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args 
     __builtin_amdgcn_s_barrier();
 
     bf16x8 xa[2], xb[2];
-    int xs = 0, d = 0;                             // ring slots of X row r / dY row r
-    load_x(xs, 0, xa);
+    load_x(0, 0, xa);
     load_dy(X_BYTES + DROW, dp);                   // r = ya-1: dY row ya is the only one of the window inside the band
     load_dy(ZERO_IMG, dc);
     load_dy(ZERO_IMG, dm);
-    // one row step; `xa` holds X(r)[kw = 0]; on return `xb` holds X(r+1)[kw = 0]
-    auto row_step = [&](int r, bf16x8 (&xa)[2], bf16x8 (&xb)[2]) {
-      load_x(xs, 1, xb);
+    // One row step; `xa` holds X(r)[kw = 0]; on return `xb` holds X(r+1)[kw = 0].  The ring slot S of row r is a COMPILE-TIME
+    // constant (four step bodies per trip), so every LDS offset of the step is an instruction immediate.
+    auto row_step = [&](int r, auto slot_tag, bf16x8 (&xa)[2], bf16x8 (&xb)[2]) {
+      constexpr int S = decltype(slot_tag)::value;
+      load_x(S, 1, xb);
       mfma12(0, xa);
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);      // the next tap column's fragments first, then this one's MFMAs
       __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
       // row r+3 is fetched from inside the MFMA stream (its address arithmetic runs in the matrix pipe's shadow), always:
       // past the band it brings zeros / unused rows into ring slots that are dead by then, which keeps vmcnt uniform
-      issue_next((xs + 3) & (NRX - 1), wrap(d + 3, NRD));      // row r + 3
-      load_x(xs, 2, xa);
+      issue_next((S + 3) & 3, (S + 3) & 3);                   // row r + 3
+      load_x(S, 2, xa);
       mfma12(1, xb);
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
       __builtin_amdgcn_sched_group_barrier(0x008, 12, 1);
@@ -209,10 +211,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args 
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every read of X row r has returned: its slot is reused by row r+4
       wait_vmcnt<3>();                                        // rows <= r+2 have landed
       __builtin_amdgcn_s_barrier();
-      const int on = r + 2 < yb ? X_BYTES + wrap(d + 2, NRD) * DROW : ZERO_IMG;      // dY row r+2 (or the zero image)
-      xs = (xs + 1) & (NRX - 1);
-      d = wrap(d + 1, NRD);
-      load_x(xs, 0, xb);                                      // (past the last row: harmless reads, never used)
+      const int on = r + 2 < yb ? X_BYTES + ((S + 2) & 3) * DROW : ZERO_IMG;      // dY row r+2 (or the zero image)
+      load_x((S + 1) & 3, 0, xb);                             // (past the last row: harmless reads, never used)
       load_dy(on, dn);
       mfma12(2, xa);
       __builtin_amdgcn_sched_group_barrier(0x100, 8, 2);
@@ -224,9 +224,20 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args 
         dp[ao] = dn[ao];
       }
     };
-    for (int r = ya - 1; r <= yb; r += 2) {         // RB is even: RB + 2 row steps, two per trip (the X register sets swap)
-      row_step(r, xa, xb);
-      row_step(r + 1, xb, xa);
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
+    using S3 = std::integral_constant<int, 3>;
+    int r = ya - 1;                                 // RB is even: RB + 2 row steps; the X register sets swap every step
+    for (; r + 3 <= yb; r += 4) {
+      row_step(r, S0{}, xa, xb);
+      row_step(r + 1, S1{}, xb, xa);
+      row_step(r + 2, S2{}, xa, xb);
+      row_step(r + 3, S3{}, xb, xa);
+    }
+    if (r <= yb) {                                  // (RB + 2) % 4 == 2: the ring is back at slot 0 here
+      row_step(r, S0{}, xa, xb);
+      row_step(r + 1, S1{}, xb, xa);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     wait_vmcnt<0>();                               // (the trailing rows issued past the band)

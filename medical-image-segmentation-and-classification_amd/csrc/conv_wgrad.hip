@@ -225,7 +225,12 @@ extern "C" int mi355_conv2d_wgrad_splits(int N, int Ho, int Wo, int Ci, int Co, 
     const int rb = Ho % 32 == 0 ? 32 : (Ho % 16 == 0 ? 16 : 8);
     const long long items = (long long)N * (Wo / 32) * (Ho / rb);
     const long long tiles = (long long)ceil_div(Co, 64) * ceil_div(Ci, 64);
-    long long s = 512 / tiles;                 // 2 workgroups per CU are resident (216 VGPRs): one full wave of blocks
+    // ONE workgroup per CU.  Two are resident (254 VGPRs) and run the kernel 18 % faster on its own (3.4 vs 4.0 ms per
+    // Attention U-Net step), but the kernel lives on the side stream next to the data-gradient chain: at one per CU it leaves
+    // half of every SIMD's registers to the main stream's kernels, the two interleave instead of queueing, and half as many
+    // partial slabs reach the reduce.  Step: 512 / 384 / 320 / 256 / 192 / 128 workgroups = 18.53 / 18.58 / 18.47 / 18.18 /
+    // 18.28 / 19.28 ms.
+    long long s = 256 / tiles;
     if (s > items) s = items;
     const long long slab = (long long)Co * 9 * Ci * 4;
     while (s > 1 && s * slab > (512ll << 20)) --s;
@@ -235,7 +240,7 @@ extern "C" int mi355_conv2d_wgrad_splits(int N, int Ho, int Wo, int Ci, int Co, 
   wgrad_tiles(Co, Ci, bco, bci);
   const long long M = (long long)N * Ho * Wo;
   const long long tiles = (long long)ceil_div(Co, bco) * ceil_div(Ci, bci) * KH * KW;
-  long long s = 1536 / tiles;                          // ~6 workgroups per CU in flight
+  long long s = 768 / tiles;                           // ~3 workgroups per CU (1536: same kernel time, more partials to reduce)
   const long long max_by_pixels = M / 256 > 0 ? M / 256 : 1;
   if (s > max_by_pixels) s = max_by_pixels;
   const long long slab = (long long)Co * KH * KW * Ci * 4;

@@ -230,7 +230,7 @@ def test_conv_fused_bn_statistics(case, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("ci,co", [(64, 32), (32, 64), (128, 64), (64, 128), (64, 64), (32, 32)])
-@pytest.mark.parametrize("nhw", [(3, 9, 7), (2, 40, 37)])
+@pytest.mark.parametrize("nhw", [(3, 9, 7), (2, 40, 37), (1, 3, 3), (1, 1, 2)])      # 189 / 2960 / 9 / 2 pixels (idle waves, one ragged block)
 def test_pointwise_stream_kernel(nhw, ci, co, dtype):
     """Narrow 1x1 convolutions run on conv1x1_stream_kernel (variant 4): ragged pixel counts, bias + ReLU + fused statistics,
     then the same call reading / accumulating into channel slices of wider buffers (the data-gradient use)."""

@@ -26,36 +26,51 @@ template <typename T> struct BnStatsOp {
 
 // ---- folding per-workgroup partials -----------------------------------------------------------------
 // Finalize kernels run 1024-thread workgroups of CH channels x BL row lanes: thread (bl, cl) sums partial
-// rows b = bl, bl+BL, ... for channel c0+cl, then the row lanes are folded through LDS.  <32,32> for the
-// row-reduce partials (<= 1024 rows); <4,256> when a conv epilogue produced one row per M tile (thousands).
-template <int CH, int BL>
-__device__ __forceinline__ double fold_partials(const float* __restrict__ partial, int nblocks, int rowlen, int off, int C,
-                                                double* red) {
+// rows b = bl, bl+BL, ... for channel c0+cl (fp64, four independent loads in flight), for NQ quantities at once
+// (column offsets off[q]); the row lanes of a wave are then folded with shuffles and the 16 waves through ONE
+// LDS exchange (one barrier instead of the 2 x log2(BL) of a shared-memory tree: these kernels are pure
+// latency on the critical path, ~70 launches per step).  <32,32> for the row-reduce partials of narrow grids;
+// <4,256> when there are more than 128 partial rows.  The sums are valid in threads tid < CH.
+template <int CH, int BL, int NQ>
+__device__ __forceinline__ void fold_partials(const float* __restrict__ partial, int nblocks, int rowlen, const int (&off)[NQ], int C,
+                                              double* red /* [NQ][16][CH] */, double (&out)[NQ]) {
+  static_assert(CH * BL == 1024 && CH <= 64 && (CH & (CH - 1)) == 0, "1024-thread workgroup, power-of-two channel count");
   const int cl = threadIdx.x % CH, bl = threadIdx.x / CH;
   const int c = blockIdx.x * CH + cl;
-  double s = 0;
-  if (c < C) {
-    double s1 = 0, s2 = 0, s3 = 0;
-    int b = bl;
-    for (; b + 3 * BL < nblocks; b += 4 * BL) {      // four independent loads in flight
-      s += (double)partial[(size_t)b * rowlen + off + c];
-      s1 += (double)partial[(size_t)(b + BL) * rowlen + off + c];
-      s2 += (double)partial[(size_t)(b + 2 * BL) * rowlen + off + c];
-      s3 += (double)partial[(size_t)(b + 3 * BL) * rowlen + off + c];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double s[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    if (c < C) {
+      const float* p = partial + off[q] + c;
+      int b = bl;
+      for (; b + 3 * BL < nblocks; b += 4 * BL) {
+        s0 += (double)p[(size_t)b * rowlen];
+        s1 += (double)p[(size_t)(b + BL) * rowlen];
+        s2 += (double)p[(size_t)(b + 2 * BL) * rowlen];
+        s3 += (double)p[(size_t)(b + 3 * BL) * rowlen];
+      }
+      for (; b < nblocks; b += BL) s0 += (double)p[(size_t)b * rowlen];
     }
-    for (; b < nblocks; b += BL) s += (double)partial[(size_t)b * rowlen + off + c];
-    s += s1 + s2 + s3;
+    s[q] = (s0 + s1) + (s2 + s3);
   }
-  red[bl * CH + cl] = s;
-  __syncthreads();
-  // log-step fold over the BL row lanes (every thread participates; result in row lane 0)
-  for (int st = BL / 2; st > 0; st >>= 1) {
-    if (bl < st) red[bl * CH + cl] += red[(bl + st) * CH + cl];
-    __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+    for (int m = CH; m < 64; m <<= 1) s[q] += __shfl_xor(s[q], m, 64);      // the 64 / CH row lanes of this wave
+    if (lane < CH) red[(q * 16 + wave) * CH + lane] = s[q];
   }
-  const double t = red[cl];
   __syncthreads();
-  return t;     // valid for threads with bl == 0 (all threads read the same value)
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    double t = 0;
+    if (threadIdx.x < CH) {
+#pragma unroll
+      for (int w = 0; w < 16; ++w) t += red[(q * 16 + w) * CH + threadIdx.x];
+    }
+    out[q] = t;
+  }
 }
 
 extern "C" int mi355_rowreduce_blocks(long long M) { return rowreduce_blocks(M); }
@@ -75,9 +90,10 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                    float* __restrict__ rmean, float* __restrict__ rvar, int64_t* nbt, float momentum,
                                    float eps, float* __restrict__ scale, float* __restrict__ shift,
                                    float* __restrict__ mean_out, float* __restrict__ invstd_out) {
-  __shared__ double red[CH * BL];
-  const double s = fold_partials<CH, BL>(partial, nblocks, 2 * C, 0, C, red);
-  const double q = fold_partials<CH, BL>(partial, nblocks, 2 * C, C, C, red);
+  __shared__ double red[2 * 16 * CH];
+  double sums2[2];
+  fold_partials<CH, BL, 2>(partial, nblocks, 2 * C, {0, C}, C, red, sums2);
+  const double s = sums2[0], q = sums2[1];
   const int c = blockIdx.x * CH + threadIdx.x;
   if (threadIdx.x >= CH) return;
   if (c == 0 && nbt) *nbt += 1;
@@ -298,9 +314,10 @@ template <int CH, int BL>
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int C,
                                                                float* __restrict__ sums, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, float accf) {
-  __shared__ double red[CH * BL];
-  const double s0 = fold_partials<CH, BL>(partial, nblocks, 2 * C, 0, C, red);
-  const double s1 = fold_partials<CH, BL>(partial, nblocks, 2 * C, C, C, red);
+  __shared__ double red[2 * 16 * CH];
+  double sums2[2];
+  fold_partials<CH, BL, 2>(partial, nblocks, 2 * C, {0, C}, C, red, sums2);
+  const double s0 = sums2[0], s1 = sums2[1];
   const int c = blockIdx.x * CH + threadIdx.x;
   if (threadIdx.x >= CH || c >= C) return;
   sums[c] = (float)s0;
@@ -414,8 +431,10 @@ extern "C" int mi355_colsum(const void* x, int ld, float* partial, long long M, 
 
 __global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nblocks, int stride, int C,
                                        float* __restrict__ out, float accf) {
-  __shared__ double red[32 * 32];
-  const double s0 = fold_partials<32, 32>(partial, nblocks, stride * C, 0, C, red);
+  __shared__ double red[16 * 32];
+  double sums1[1];
+  fold_partials<32, 32, 1>(partial, nblocks, stride * C, {0}, C, red, sums1);
+  const double s0 = sums1[0];
   const int c = blockIdx.x * 32 + threadIdx.x;
   if (threadIdx.x >= 32 || c >= C) return;
   out[c] = (accf != 0.f ? accf * out[c] : 0.f) + (float)s0;

@@ -155,18 +155,47 @@ __global__ __launch_bounds__(256) void pack_weight_batched_kernel(const long lon
       for (int e = lane; e < len; e += 64) tile[r * PITCH + e] = (a < A && e < nbv) ? src[e] * f : 0.f;
     }
     __syncthreads();
+    // 2-byte packs leave as 16-byte stores (eight consecutive inner elements per lane, the index arithmetic once per eight)
+    // whenever the tile and the row pitch allow it; ragged tiles and fp32 take the element loop
+    constexpr int V = 16 / (int)sizeof(T);
+    const bool vec_b = sizeof(T) == 2 && nb % V == 0 && Bp % V == 0 && b0 % V == 0;
+    const bool vec_a = sizeof(T) == 2 && na % V == 0 && Ap % V == 0 && a0 % V == 0;
     if (out_b) {
-      const int n = na * taps * nb;
-      for (int i = tid; i < n; i += 256) {
-        const int bb = i % nb, tap = (i / nb) % taps, r = i / (nb * taps);
-        out_b[((size_t)(a0 + r) * taps + tap) * Bp + b0 + bb] = from_f32<T>(tile[r * PITCH + bb * taps + tap]);
+      if (vec_b) {
+        const int nbv8 = nb / V, n = na * taps * nbv8;
+        for (int i = tid; i < n; i += 256) {
+          const int b8 = i % nbv8, tap = (i / nbv8) % taps, r = i / (nbv8 * taps);
+          const float* src = tile + r * PITCH + b8 * V * taps + tap;
+          Vec16<T> v;
+#pragma unroll
+          for (int e = 0; e < V; ++e) v.v[e] = from_f32<T>(src[e * taps]);
+          st16<T>(out_b + ((size_t)(a0 + r) * taps + tap) * Bp + b0 + b8 * V, v);
+        }
+      } else {
+        const int n = na * taps * nb;
+        for (int i = tid; i < n; i += 256) {
+          const int bb = i % nb, tap = (i / nb) % taps, r = i / (nb * taps);
+          out_b[((size_t)(a0 + r) * taps + tap) * Bp + b0 + bb] = from_f32<T>(tile[r * PITCH + bb * taps + tap]);
+        }
       }
     }
     if (out_a) {
-      const int n = nb * taps * na;
-      for (int i = tid; i < n; i += 256) {
-        const int r = i % na, tap = (i / na) % taps, bb = i / (na * taps);
-        out_a[((size_t)(b0 + bb) * taps + tap) * Ap + a0 + r] = from_f32<T>(tile[r * PITCH + bb * taps + tap]);
+      if (vec_a) {
+        const int na8 = na / V, n = nb * taps * na8;
+        for (int i = tid; i < n; i += 256) {
+          const int r8 = i % na8, tap = (i / na8) % taps, bb = i / (na8 * taps);
+          const float* src = tile + r8 * V * PITCH + bb * taps + tap;
+          Vec16<T> v;
+#pragma unroll
+          for (int e = 0; e < V; ++e) v.v[e] = from_f32<T>(src[e * PITCH]);
+          st16<T>(out_a + ((size_t)(b0 + bb) * taps + tap) * Ap + a0 + r8 * V, v);
+        }
+      } else {
+        const int n = nb * taps * na;
+        for (int i = tid; i < n; i += 256) {
+          const int r = i % na, tap = (i / na) % taps, bb = i / (na * taps);
+          out_a[((size_t)(b0 + bb) * taps + tap) * Ap + a0 + r] = from_f32<T>(tile[r * PITCH + bb * taps + tap]);
+        }
       }
     }
   }

@@ -67,8 +67,9 @@ def test_fold_rows(rows, rowlen, nsplit):
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("act,with_res", [(1, False), (0, False), (1, True)])
-def test_bn_backward(dtype, act, with_res):
-    n, c, h, w = 3, 64, 10, 6
+@pytest.mark.parametrize("shape", [(3, 64, 10, 6), (5, 32, 72, 72)])      # 180 rows; 25 920 rows: 405 partial rows from a 256-workgroup grid
+def test_bn_backward(dtype, act, with_res, shape):
+    n, c, h, w = shape
     g = torch.Generator().manual_seed(5 + act)
     x = q(torch.randn(n, c, h, w, generator=g) * 1.5 + 0.3, dtype).requires_grad_(True)
     res = q(torch.randn(n, c, h, w, generator=g), dtype).requires_grad_(True)

@@ -345,6 +345,61 @@ def test_test_all_models_walks_the_weight_directories(tmp_path, capsys):
     assert (tmp_path / "s.csv").read_text().startswith("Model,iou,dice,pixel_accuracy,precision,recall,f1\nAttentionUNet,")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_resume_from_checkpoint_is_bit_exact(tmp_path, dtype):
+    """N3: a run restarted from {model, optimiser, loss scaler} state dicts written with torch.save
+    continues exactly where the uninterrupted run goes — weights, BatchNorm buffers and AdamW moments bit for bit (the
+    kernels reduce in fixed orders).  The reference's own checkpoint is the model state_dict alone (helpers.py:394-400)."""
+    from mi355 import amp as mamp, nn as mnn, optim as moptim
+    from models.segmentation_models.AttentionUNet import AttentionUNet
+    batches = [otrain.synthetic_batch(2, 32, seed=s) for s in range(4)]
+
+    def make(state=None):
+        torch.manual_seed(3)
+        m = AttentionUNet()
+        m.compute_dtype = dtype
+        m = m.to(DEV).train()
+        opt = moptim.AdamW(m.parameters(), lr=1e-3, weight_decay=5e-4)
+        sc = mamp.GradScaler(enabled=dtype == torch.float16)
+        if state is not None:
+            m.load_state_dict(state["model"])
+            opt.load_state_dict(state["opt"])
+            sc.load_state_dict(state["scaler"])
+        return m, opt, sc
+
+    def run(m, opt, sc, bs):
+        crit = mnn.BCEWithLogitsLoss()
+        for x, y in bs:
+            opt.zero_grad(set_to_none=True)
+            loss = crit(m(x.to(DEV)), y.to(DEV))
+            sc.scale(loss).backward()
+            sc.unscale_(opt)
+            moptim.clip_grad_norm_(m.parameters(), max_norm=1.0)
+            sc.step(opt)
+            sc.update()
+        torch.cuda.synchronize()
+
+    m, opt, sc = make()
+    run(m, opt, sc, batches)
+    want = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    want_opt = opt.state_dict()
+
+    m, opt, sc = make()
+    run(m, opt, sc, batches[:2])
+    torch.save({"model": m.state_dict(), "opt": opt.state_dict(), "scaler": sc.state_dict()}, tmp_path / "ckpt.pt")
+    del m, opt, sc
+    m, opt, sc = make(torch.load(tmp_path / "ckpt.pt", map_location=DEV))
+    run(m, opt, sc, batches[2:])
+    got = m.state_dict()
+    for k, v in want.items():
+        assert torch.equal(got[k].cpu(), v), k
+    go = opt.state_dict()
+    for i, st in want_opt["state"].items():
+        for key in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(go["state"][i][key].cpu(), st[key].cpu()), (i, key)
+        assert float(go["state"][i]["step"]) == float(st["step"]) == 4.0
+
+
 def _pool_gap(sd64, x):
     """smallest relative gap between the two largest values of a 2x2 max-pool window (positive maximum) anywhere in
     the VGG16_BN feature stack, evaluated in fp64"""

@@ -155,6 +155,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # stdout carries exactly ONE line (the JSON, rank 0): libraries that print banners to fd 1 (RCCL prints "Hostname : ..." /
+    # "Librccl path : ..." when the communicator is created) are pointed at stderr for the rest of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_dp = world > 1 or args.force_dp
@@ -295,7 +300,8 @@ def main():
         log("per-kernel profile done; timing the CPU oracle baseline")
         result["cpu_baseline"] = cpu_baseline(args.size, 2, 2)
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
     if use_dp:
         dist.destroy_process_group()
 

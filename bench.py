@@ -303,6 +303,8 @@ def main():
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(result) + "\n").encode())
     if use_dp:
+        if world > 1:
+            dist.barrier()      # rank 0 has been profiling on its own: tear the communicator down together
         dist.destroy_process_group()
 
 

@@ -39,10 +39,14 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
 // reads per 36 MFMAs (a dY-row-major loop on 32x32x16 needed 20 per 18 twice as large ones and was 13 % slower).  A row step runs in three phases
 // by tap column kw (12 MFMAs each), the X fragments of the next phase loading while the current one computes; the
 // workgroup barrier sits between phases 1 and 2, so that the first fragments of the next row load behind phase 2.
-template <typename T>
+// W16: images 16 pixels wide.  A 32-pixel "row" is then row y of TWO images side by side (work item = image pair x row band):
+// the X row image holds two 24-pixel segments (16 + 4 + 4 halo each, so that the kw shifts of one image never read the other),
+// the dY row image the two 16-pixel rows back to back; lanes of the upper half of a K block (c4 >= 2) read the second segment.
+template <typename T, bool W16 = false>
 __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args a) {
   static_assert(sizeof(T) == 2, "bf16 / fp16 only");
-  constexpr int XPX = 40, XROW = XPX * 128, DROW = 32 * 128;
+  constexpr int XPX = W16 ? 48 : 40, XROW = XPX * 128, DROW = 32 * 128;
+  constexpr int XPIECES = XPX / 8;                   // 1-KiB DMA pieces per X row: waves 0..3, then waves 0 .. XPIECES-5
   constexpr int NRX = 4, NRD = 4;      // equal ring depths: X row q and dY row q share the slot index (q - (ya-1)) & 3
   constexpr int X_BYTES = NRX * XROW, D_BYTES = NRD * DROW;
   constexpr int ZERO_IMG = X_BYTES + D_BYTES;
@@ -64,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args 
   auto swz = [](int px) { return (((px >> 1) & 1) | (((px >> 3) & 1) << 1)) << 1; };     // XOR on the 16-B chunk index
 
   const int lpx = lane >> 3, slot = lane & 7;       // DMA: a 1-KiB piece = 8 pixels x 128 B; lane -> (pixel, 16-B slot)
-  const int TXN = a.W / 32, BANDS = a.H / a.RB;
+  const int TXN = W16 ? 1 : a.W / 32, BANDS = a.H / a.RB;
   *reinterpret_cast<uint4*>(dump + tid * 16) = make_uint4(0, 0, 0, 0);      // the all-zero dY row image
 
   f32x4 acc[9][2][2];
@@ -78,6 +82,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args 
   // transpose-read lane geometry: 16-lane block b = c4 reads pixels 8b + tq (+4), channels col0 + 4*tp .. +3
   const int tq = l16 >> 2, tp = l16 & 3;
   const int pl = 8 * c4 + tq;                      // this lane's first pixel inside a 32-pixel K block
+  const int plx = W16 ? (c4 >> 1) * 24 + 8 * (c4 & 1) + tq : pl;      // ... and inside the X row image (minus the 4-pixel halo)
   auto rd = [&](int img_off, int px, int col) {
     const int chunk = (col >> 3) ^ swz(px);
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(lds + img_off + px * 128 + chunk * 16 + (col & 7) * 2));
@@ -96,32 +101,44 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args 
     const int tx = t % TXN;
     const int n = t / TXN;
     const int ya = band * a.RB, yb = ya + a.RB, x0 = tx * 32;
+    const int nbase = W16 ? 2 * n : n;              // (W16: `n` counts image pairs)
+    // per-lane pixel geometry of this item, shared by the prologue rows and the running pointers below
+    const int px_d = 8 * wave + lpx;                 // pixel of the 32-px dY row image
+    const int c_d = co0 + 8 * (slot ^ swz(px_d));
+    const bool lane_ok_d = c_d < a.Co;
+    const int dpix = W16 ? (px_d >> 4) * a.H * a.W + (px_d & 15) : x0 + px_d;      // pixel offset from (image nbase, row r, x 0)
+    int xpix[2], c_x[2], xpiece[2];
+    bool lane_ok_x[2], real_x[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      xpiece[k] = k == 0 ? wave : 4 + wave;
+      real_x[k] = xpiece[k] < XPIECES;               // (the others write a scratch KiB: every wave issues the same count)
+      const int q = 8 * xpiece[k] + lpx;             // pixel of the X row image
+      const int half = W16 ? q / 24 : 0;
+      const int xx = W16 ? q % 24 - 4 : x0 - 4 + q;
+      c_x[k] = ci0 + 8 * (slot ^ swz(q));
+      lane_ok_x[k] = real_x[k] && (unsigned)xx < (unsigned)a.W && c_x[k] < a.Ci;
+      xpix[k] = half * a.Hi * a.Wi + (xx >> a.up);
+    }
 
     auto issue_row = [&](int r, int xs, int ds) {   // xs / ds: ring slots of X row r / dY row r
       {
-        const int px = 8 * wave + lpx;
-        const int c = co0 + 8 * (slot ^ swz(px));
-        const bool ok = r >= ya && r < yb && c < a.Co;
-        const char* p = ok ? reinterpret_cast<const char*>(dy + ((size_t)(n * a.H + r) * a.W + x0 + px) * a.ldy + c) : zero + slot * 16;
+        const bool ok = lane_ok_d && r >= ya && r < yb;
+        const char* p = ok ? reinterpret_cast<const char*>(dy + ((size_t)(nbase * a.H + r) * a.W + dpix) * a.ldy + c_d) : zero + slot * 16;
         dma16(p, lds_addr(dr + ds * DROW + wave * 1024));
       }
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        const int piece = k == 0 ? wave : 4;
-        const bool real = k == 0 || wave == 0;
-        const int px = 8 * piece + lpx;              // pixel of the 40-px row image; image x = x0 - 4 + px
-        const int xx = x0 - 4 + px;
-        const int c = ci0 + 8 * (slot ^ swz(px));
-        const bool ok = real && (unsigned)r < (unsigned)a.H && (unsigned)xx < (unsigned)a.W && c < a.Ci;
-        const char* p = ok ? reinterpret_cast<const char*>(x + ((size_t)(n * a.Hi + (r >> a.up)) * a.Wi + (xx >> a.up)) * a.ldx + c)
+        const bool ok = lane_ok_x[k] && (unsigned)r < (unsigned)a.H;
+        const char* p = ok ? reinterpret_cast<const char*>(x + ((size_t)(nbase * a.Hi + (r >> a.up)) * a.Wi + xpix[k]) * a.ldx + c_x[k])
                            : zero + slot * 16;
-        dma16(p, lds_addr(real ? xr + xs * XROW + piece * 1024 : dump + wave * 1024));
+        dma16(p, lds_addr(real_x[k] ? xr + xs * XROW + xpiece[k] * 1024 : dump + wave * 1024));
       }
     };
     // X fragments of tap column kw: [ci block]; dY fragments of a row: [co block]
     auto load_x = [&](int xs, int kw, bf16x8 (&bf)[2]) {
 #pragma unroll
-      for (int bi = 0; bi < 2; ++bi) bf[bi] = frag(xs * XROW, pl + 3 + kw, colB + 16 * bi);
+      for (int bi = 0; bi < 2; ++bi) bf[bi] = frag(xs * XROW, plx + 3 + kw, colB + 16 * bi);
     };
     auto load_dy = [&](int off, bf16x8 (&af)[2]) {
 #pragma unroll
@@ -141,24 +158,13 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args 
     // The rows the main loop fetches are CONSECUTIVE (ya + 2, ya + 3, ...): their per-lane source pointers advance by a row
     // stride instead of being rebuilt from (n, r, x) with 64-bit multiplies each time, and the lane part of the bounds test
     // (channel / image-column range) is taken once per item; only the row part, wave-uniform, is evaluated per row.
-    const int px_d = 8 * wave + lpx;
-    const int c_d = co0 + 8 * (slot ^ swz(px_d));
-    const bool lane_ok_d = c_d < a.Co;
-    const int off_d = ((x0 + px_d) * a.ldy + c_d) * (int)sizeof(T);            // per-lane byte offset inside a dY row (32 bit)
-    const char* drow_next = reinterpret_cast<const char*>(dy + (size_t)(n * a.H + ya + 2) * a.W * a.ldy);      // wave-uniform
+    const int off_d = (dpix * a.ldy + c_d) * (int)sizeof(T);                  // per-lane byte offset from the row base (32 bit)
+    const char* drow_next = reinterpret_cast<const char*>(dy + (size_t)(nbase * a.H + ya + 2) * a.W * a.ldy);      // wave-uniform
     const size_t d_stride = (size_t)a.W * a.ldy * sizeof(T);
     int off_x[2];
-    bool lane_ok_x[2];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int piece = k == 0 ? wave : 4;
-      const int px = 8 * piece + lpx;
-      const int xx = x0 - 4 + px;
-      const int c = ci0 + 8 * (slot ^ swz(px));
-      lane_ok_x[k] = (k == 0 || wave == 0) && (unsigned)xx < (unsigned)a.W && c < a.Ci;
-      off_x[k] = ((xx >> a.up) * a.ldx + c) * (int)sizeof(T);
-    }
-    const char* xrow_next = reinterpret_cast<const char*>(x + (size_t)(n * a.Hi + ((ya + 2) >> a.up)) * a.Wi * a.ldx);
+    for (int k = 0; k < 2; ++k) off_x[k] = (xpix[k] * a.ldx + c_x[k]) * (int)sizeof(T);
+    const char* xrow_next = reinterpret_cast<const char*>(x + (size_t)(nbase * a.Hi + ((ya + 2) >> a.up)) * a.Wi * a.ldx);
     const size_t x_stride = (size_t)a.Wi * a.ldx * sizeof(T);
     int r_next = ya + 2;
     auto issue_next = [&](int xs, int ds) {          // row r_next into ring slots xs / ds, then advance
@@ -169,11 +175,9 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args 
       }
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        const int piece = k == 0 ? wave : 4;
-        const bool real = k == 0 || wave == 0;
         const bool ok = lane_ok_x[k] && (unsigned)r_next < (unsigned)a.H;
         const char* p = ok ? xrow_next + off_x[k] : zero + slot * 16;
-        dma16(p, lds_addr(real ? xr + xs * XROW + piece * 1024 : dump + wave * 1024));
+        dma16(p, lds_addr(real_x[k] ? xr + xs * XROW + xpiece[k] * 1024 : dump + wave * 1024));
       }
       drow_next += d_stride;
       if (!a.up || (r_next & 1)) xrow_next += x_stride;      // the source row of an up-sampled input advances every second row

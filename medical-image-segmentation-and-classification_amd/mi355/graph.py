@@ -483,7 +483,7 @@ class Builder:
 
     def wgrad_tag(self, co, ci, k=1, s=1, Ho=0, Wo=0):
         t = "f32" if self.dtype == torch.float32 else "bf16"       # (the fp16 build runs the same variants as bf16)
-        if t == "bf16" and k == 3 and s == 1 and Wo % 32 == 0 and Ho % 8 == 0:
+        if t == "bf16" and k == 3 and s == 1 and Ho % 8 == 0 and (Wo % 32 == 0 or Wo == 16):      # (Wo == 16: even batches)
             return "wgrad3x3_halo_kernel"
         return f"conv_wgrad_kernel<{t},{128 if co % 128 == 0 else 64},{128 if ci % 128 == 0 else 64}>"
 

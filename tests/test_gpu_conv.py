@@ -134,6 +134,11 @@ WG_CASES = [  # N, Ci, H, W, Co, K, stride, pad, up
     (2, 64, 16, 32, 64, 3, 1, 1, 0),
     (1, 32, 8, 64, 96, 3, 1, 1, 0),
     (2, 64, 8, 32, 32, 3, 1, 1, 0),
+    # 16-pixel-wide images, two at a time: an odd pair count, channel tails, an 8-row image, fused up-sampling (Wi = 8)
+    (6, 64, 16, 16, 64, 3, 1, 1, 0),
+    (4, 96, 8, 16, 160, 3, 1, 1, 0),
+    (2, 64, 8, 8, 64, 3, 1, 1, 1),
+    (3, 64, 16, 16, 64, 3, 1, 1, 0),      # odd batch: stays on the generic kernel
     (2, 128, 8, 16, 64, 3, 1, 1, 1),
     (1, 192, 40, 32, 128, 3, 1, 1, 0),
     (3, 64, 32, 96, 64, 3, 1, 1, 0),

@@ -152,10 +152,13 @@ int mi355_bn_bwd_reduce(const void* dy, int lddy, const void* y, int ldy, const 
 int mi355_bn_bwd_finalize(const float* partial, int nblocks, int C, float* sums, float* dgamma, float* dbeta,
                           float acc, mi355_stream_t s);
 /* dx = gamma*invstd*(g - sum_g/M - xhat*sum_gx/M); optional dres = g (residual / second operand
- * gradient, pre-normalisation), optional bias-gradient partials (column sums of dx). */
+ * gradient, pre-normalisation: the ReLU mask applied); optional dpost (+)= dy, the UNMASKED incoming gradient, for an
+ * operand that was added AFTER the activation (x + relu(bn(.)), R2AttU_Net.py:44; post_acc != 0 accumulates) — the
+ * pass reads dy anyway; optional bias-gradient partials (column sums of dx). */
 int mi355_bn_bwd_apply(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,
                        const float* gamma, const float* mean, const float* invstd, const float* mscale,
-                       const float* mshift, const float* sums, void* dx, int lddx, void* dres, int lddres, float* dbias_partial,
+                       const float* mshift, const float* sums, void* dx, int lddx, void* dres, int lddres,
+                       void* dpost, int lddpost, int post_acc, float* dbias_partial,
                        long long M, int C, int act, int dtype, mi355_stream_t s);
 /* out[c] (+)= sum_b partial[b*stride*C + c]  (used for conv bias gradients). */
 int mi355_colsum_finalize(const float* partial, int nblocks, int stride, int C, float* out, float acc,

@@ -346,7 +346,7 @@ template <typename T> struct BnBwdApplyOp {
   static constexpr int EPC = 16 / (int)sizeof(T);
   const T* dy; int lddy; const T* y; int ldy; const T* x; int ldx;
   const float* gamma; const float* mean; const float* invstd; const float* mscale; const float* mshift; const float* sums;
-  T* dx; int lddx; T* dres; int lddres;
+  T* dx; int lddx; T* dres; int lddres; T* dpost; int lddpost; int post_acc;
   float invM; int C; int act;
   float mu[EPC], is[EPC], k0[EPC], k1[EPC], gi[EPC], ms[EPC], mt[EPC];
   __device__ void load_cols(int c0) {
@@ -362,15 +362,24 @@ template <typename T> struct BnBwdApplyOp {
     }
   }
   static constexpr int FETCH_ROWS = 4;
-  struct In { Vec16<T> g, xv, yv; };
+  struct In { Vec16<T> g, xv, yv, pv; };
   __device__ In fetch(size_t row, int c0) const {
     In in;
     in.g = ld16<T>(dy + row * lddy + c0);
     in.xv = ld16<T>(x + row * ldx + c0);
     if (act && y) in.yv = ld16<T>(y + row * ldy + c0);
+    if (dpost && post_acc) in.pv = ld16<T>(dpost + row * lddpost + c0);
     return in;
   }
   __device__ void finish(const In& in, size_t row, int c0, Acc (&acc)[NQ][EPC]) const {
+    if (dpost) {      // gradient of an operand added after the activation: the incoming gradient itself
+      Vec16<T> pg = in.g;
+      if (post_acc) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) pg.v[e] = from_f32<T>(to_f32<T>(in.g.v[e]) + to_f32<T>(in.pv.v[e]));
+      }
+      st16<T>(dpost + row * lddpost + c0, pg);
+    }
     Vec16<T> o, r;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
@@ -394,13 +403,14 @@ template <typename T> struct BnBwdApplyOp {
 extern "C" int mi355_bn_bwd_apply(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,
                                   const float* gamma, const float* mean, const float* invstd, const float* mscale,
                                   const float* mshift, const float* sums, void* dx, int lddx, void* dres, int lddres,
+                                  void* dpost, int lddpost, int post_acc,
                                   float* dbias_partial, long long M, int C, int act, int dtype, mi355_stream_t s) {
   MI355_CHECK_ARG(dy && x && gamma && mean && invstd && sums && dx && (!act || y || (mscale && mshift)), "bn_bwd_apply: null pointer");
   const float invM = (float)(1.0 / (double)M);
   return dispatch_dtype(dtype, "bn_bwd_apply", [&](auto tag) {
     using T = decltype(tag);
     BnBwdApplyOp<T> op{(const T*)dy, lddy, (const T*)y, ldy, (const T*)x, ldx, gamma, mean, invstd,
-                       mscale, mshift, sums, (T*)dx, lddx, (T*)dres, lddres, invM, C, act};
+                       mscale, mshift, sums, (T*)dx, lddx, (T*)dres, lddres, (T*)dpost, lddpost, post_acc, invM, C, act};
     return rowred_launch<T>(op, M, C, dbias_partial, (hipStream_t)s);
   });
 }

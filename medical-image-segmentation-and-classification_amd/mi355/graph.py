@@ -524,7 +524,7 @@ class Builder:
                                    C, st["scale"], st["shift"]))
         return st
 
-    def _bn_bwd(self, da, a, y, bn, st, act, dres_to=None, bias=None):
+    def _bn_bwd(self, da, a, y, bn, st, act, dres_to=None, bias=None, post_to=None):
         """Emit BN(+ReLU) backward: returns dy (grad of the raw input y)."""
         C = bn.num_features
         nb = lib.mi355_rowreduce_blocks(y.M)
@@ -555,10 +555,17 @@ class Builder:
         if bias is not None and bias.requires_grad and id(bias) not in self._grad_first:
             self.pgrad(bias)
             self.zero_grad_params.append(bias)
+        # an operand added AFTER the activation (recurrent block x + relu(bn(.))) receives the incoming gradient itself: the
+        # apply pass reads it anyway and writes / accumulates it (no separate mi355_add pass over da)
+        pg, pacc = None, 0
+        if post_to is not None and post_to.needs_grad:
+            pacc = self.acc_flag(post_to)
+            pg = self.grad_of(post_to)
         self.bwd.append(Launch("mi355_bn_bwd_apply", da, da.ld, am, am.ld if am is not None else 0, y, y.ld, bn.weight,
                                st["mean"], st["invstd"], st["scale"], st["shift"], sums, dy, dy.ld,
-                               dres, dres.ld if dres is not None else 0, None, y.M, C, 1 if act else 0, self.code,
-                               nbytes=(3 + (am is not None) + (dres is not None)) * y.M * C * self.esz))
+                               dres, dres.ld if dres is not None else 0, pg, pg.ld if pg is not None else 0, 1 if pacc else 0,
+                               None, y.M, C, 1 if act else 0, self.code,
+                               nbytes=(3 + (am is not None) + (dres is not None) + (pg is not None) * (2 if pacc else 1)) * y.M * C * self.esz))
         if dres is not None and dres is not dres_to._grad:
             rg = self.grad_of(dres_to)
             self.bwd.append(Launch("mi355_add", rg, rg.ld, dres, dres.ld, rg, rg.ld, y.M, C, self.code))
@@ -603,11 +610,8 @@ class Builder:
             if not a.needs_grad:
                 return
             da = self.grad_of(a)
-            if post_add is not None and post_add.needs_grad:      # d(x + relu(.)) / dx = identity
-                acc = self.acc_flag(post_add)
-                pg = self.grad_of(post_add)
-                self.bwd.append(Launch("mi355_add", da, da.ld, pg if acc else None, pg.ld, pg, pg.ld, y.M, y.C, self.code))
-            dy = self._bn_bwd(da, a, y, bn, st, act, dres_to=res, bias=conv.bias)
+            # d(x + relu(.)) / dx = identity: folded into the BatchNorm apply pass
+            dy = self._bn_bwd(da, a, y, bn, st, act, dres_to=res, bias=conv.bias, post_to=post_add)
             conv_bwd(dy, bias_done=True)
         self.rule(rule)
         return a

@@ -16,7 +16,7 @@ gamma = torch.ones(C, device=dev); mean = torch.zeros(C, device=dev); inv = torc
 sc = torch.ones(C, device=dev); sh = torch.zeros(C, device=dev); sums = torch.zeros(2 * C, device=dev)
 s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
 def wg(s): lib.mi355_conv2d_wgrad(x, dy, ws, splits, N, H, W, C, C, H, W, C, C, 3, 3, 1, 1, 0, code, s.cuda_stream)
-def bn(s): lib.mi355_bn_bwd_apply(g, C, None, 0, y, C, gamma, mean, inv, sc, sh, sums, dx, C, None, 0, None, M, C, 1, code, s.cuda_stream)
+def bn(s): lib.mi355_bn_bwd_apply(g, C, None, 0, y, C, gamma, mean, inv, sc, sh, sums, dx, C, None, 0, None, 0, 0, None, M, C, 1, code, s.cuda_stream)
 def timeit(f, n=20):
     for _ in range(3): f()
     torch.cuda.synchronize(); t = time.perf_counter()

@@ -88,10 +88,12 @@ def test_bn_backward(dtype, act, with_res, shape):
     sums = torch.empty(2 * c, device=DEV); dgam = torch.ones(c, device=DEV); dbet = torch.ones(c, device=DEV)
     lib.mi355_bn_bwd_finalize(part, nb, c, sums, dgam, dbet, 1.0)      # accumulate onto ones
     dx = torch.empty_like(xd); dres = torch.empty_like(xd)
+    post0 = q(torch.randn(n, c, h, w, generator=g), dtype)      # an operand added after the activation: dpost += dy in the same pass
+    dpost = to_nhwc(post0, dtype)
     nb1, p1 = _partials(m, c, 1)
     lib.mi355_bn_bwd_apply(dyd, c, yd if with_res else None, c, xd, c, dev(gamma.detach()), dev(mu), dev(isd),
                            dev(gamma.detach() * isd), dev(beta.detach() - mu * gamma.detach() * isd), sums, dx, c,
-                           dres if with_res else None, c, p1, m, c, act, code)
+                           dres if with_res else None, c, dpost, c, 1, p1, m, c, act, code)
     dbias = torch.empty(c, device=DEV)
     lib.mi355_colsum_finalize(p1, nb1, 1, c, dbias, 0.0)
     torch.cuda.synchronize()
@@ -100,6 +102,7 @@ def test_bn_backward(dtype, act, with_res, shape):
     assert rel_err(dgam.cpu() - 1, gamma.grad) < tol and rel_err(dbet.cpu() - 1, beta.grad) < tol
     if with_res:
         assert rel_err(from_nhwc(dres), res.grad) < tol
+    assert rel_err(from_nhwc(dpost), q(post0 + q(dy, dtype), dtype)) < (1e-6 if dtype == torch.float32 else 1e-2)
     assert float(dbias.abs().max()) < 1e-2 * float(x.grad.abs().sum((0, 2, 3)).max())   # ~0: dx is mean-free
 
 

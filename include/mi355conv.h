@@ -109,6 +109,17 @@ int mi355_conv2d_wgrad(const void* x, const void* dy, float* ws, int splits,
                        int N, int Hi, int Wi, int Ci, int ldx,
                        int Ho, int Wo, int Co, int ldy,
                        int KH, int KW, int stride, int pad, int up, int dtype, mi355_stream_t s);
+/* Weight gradient of ONE 3x3 / stride 1 / pad 1 convolution that was applied `napp` (<= 6) times to different inputs — the
+ * shared convolution of a recurrent block (R2AttU_Net.py:29-45: conv(x), then five times conv(x + x1)): dW = sum over the
+ * pairs (x_i, dy_i), computed by ONE launch of the nine-tap kernel (the pairs are more work items) into ONE set of partial
+ * slabs, followed by ONE mi355_conv2d_wgrad_reduce.  All pairs share geometry and channel strides; unused pairs are NULL.
+ * Served when mi355_conv2d_wgrad_multi_ok(N, Ho, Wo, dtype) != 0 (bf16 / fp16, images divisible into the kernel's row
+ * segments); splits = mi355_conv2d_wgrad_splits(N * napp, ...), ws = splits * Co * 9 * Ci floats. */
+int mi355_conv2d_wgrad_multi_ok(int N, int Ho, int Wo, int dtype);
+int mi355_conv2d_wgrad_multi(const void* x0, const void* dy0, const void* x1, const void* dy1, const void* x2, const void* dy2,
+                             const void* x3, const void* dy3, const void* x4, const void* dy4, const void* x5, const void* dy5,
+                             int napp, float* ws, int splits, int N, int Hi, int Wi, int Ci, int ldx, int Ho, int Wo, int Co,
+                             int ldy, int up, int dtype, mi355_stream_t s);
 int mi355_conv2d_wgrad_reduce(const float* ws, int splits, float* dw, int Co, int Ci, int Ci_real,
                               int KH, int KW, int transposed, float beta, mi355_stream_t s);
 

@@ -297,11 +297,13 @@ extern "C" int mi355_conv2d_wgrad(const void* x, const void* dy, float* ws, int 
   const int hmode = halo_wgrad_mode(N, Ho, Wo, KH, KW);
   if (dtype_is_2byte(dtype) && use_halo && stride == 1 && pad == 1 && hmode && Ho == a.Hlog && Wo == a.Wlog) {
     Wgrad3Args h;
-    h.x = x; h.dy = dy; h.ws = ws;
+    for (int i = 0; i < 6; ++i) { h.xs[i] = x; h.dys[i] = dy; }
+    h.ws = ws;
     h.N = N; h.Hi = Hi; h.Wi = Wi; h.Ci = Ci; h.ldx = ldx;
     h.H = Ho; h.W = Wo; h.Co = Co; h.ldy = ldy; h.up = up ? 1 : 0;
     h.RB = Ho % 32 == 0 ? 32 : (Ho % 16 == 0 ? 16 : 8);
     h.items = hmode == 2 ? (N / 2) * (Ho / h.RB) : N * (Wo / 32) * (Ho / h.RB);
+    h.items_per_app = h.items;
     h.items_per_block = ceil_div(h.items, splits);
     dim3 grid(ceil_div(Co, 64) * ceil_div(Ci, 64), splits);
     if (hmode == 2) {
@@ -316,6 +318,50 @@ extern "C" int mi355_conv2d_wgrad(const void* x, const void* dy, float* ws, int 
   }
   return dispatch_dtype(dtype, "conv2d_wgrad", [&](auto tag) { return wgrad_launch<decltype(tag)>(a, splits, (hipStream_t)s); });
 }
+
+extern "C" int mi355_conv2d_wgrad_multi_ok(int N, int Ho, int Wo, int dtype) {
+  static const int use_halo = getenv("MI355_WGRAD_HALO") ? atoi(getenv("MI355_WGRAD_HALO")) : 1;
+  return (use_halo && dtype_is_2byte(dtype) && halo_wgrad_mode(N, Ho, Wo, 3, 3)) ? 1 : 0;
+}
+
+extern "C" int mi355_conv2d_wgrad_multi(const void* x0, const void* dy0, const void* x1, const void* dy1, const void* x2,
+                                        const void* dy2, const void* x3, const void* dy3, const void* x4, const void* dy4,
+                                        const void* x5, const void* dy5, int napp, float* ws, int splits, int N, int Hi, int Wi,
+                                        int Ci, int ldx, int Ho, int Wo, int Co, int ldy, int up, int dtype, mi355_stream_t s) {
+  const void* xs[6] = {x0, x1, x2, x3, x4, x5};
+  const void* dys[6] = {dy0, dy1, dy2, dy3, dy4, dy5};
+  MI355_CHECK_ARG(napp >= 1 && napp <= 6 && ws && splits >= 1, "conv2d_wgrad_multi: 1..6 operand pairs, a workspace, splits >= 1");
+  for (int i = 0; i < napp; ++i)
+    MI355_CHECK_ARG(xs[i] && dys[i] && ((uintptr_t)xs[i] % 16) == 0 && ((uintptr_t)dys[i] % 16) == 0,
+                    "conv2d_wgrad_multi: pair %d: null or misaligned pointer", i);
+  MI355_CHECK_ARG(mi355_conv2d_wgrad_multi_ok(N, Ho, Wo, dtype), "conv2d_wgrad_multi: shape / dtype not served by the nine-tap kernel "
+                  "(mi355_conv2d_wgrad_multi_ok == 0): run mi355_conv2d_wgrad per pair");
+  MI355_CHECK_ARG(Ci % 8 == 0 && Co % 8 == 0 && (ldx * 2) % 16 == 0 && (ldy * 2) % 16 == 0 && ldx >= Ci && ldy >= Co,
+                  "conv2d_wgrad_multi: channel counts / strides must be multiples of 8 elements");
+  MI355_CHECK_ARG((up ? (Ho == 2 * Hi && Wo == 2 * Wi) : (Ho == Hi && Wo == Wi)), "conv2d_wgrad_multi: 3x3 / stride 1 / pad 1 geometry only");
+  const int hmode = halo_wgrad_mode(N, Ho, Wo, 3, 3);
+  Wgrad3Args h;
+  for (int i = 0; i < 6; ++i) { h.xs[i] = xs[i < napp ? i : 0]; h.dys[i] = dys[i < napp ? i : 0]; }
+  h.ws = ws;
+  h.N = N; h.Hi = Hi; h.Wi = Wi; h.Ci = Ci; h.ldx = ldx;
+  h.H = Ho; h.W = Wo; h.Co = Co; h.ldy = ldy; h.up = up ? 1 : 0;
+  h.RB = Ho % 32 == 0 ? 32 : (Ho % 16 == 0 ? 16 : 8);
+  h.items_per_app = hmode == 2 ? (N / 2) * (Ho / h.RB) : N * (Wo / 32) * (Ho / h.RB);
+  h.items = napp * h.items_per_app;
+  MI355_CHECK_ARG(splits <= h.items, "conv2d_wgrad_multi: more splits (%d) than work items (%d)", splits, h.items);
+  h.items_per_block = ceil_div(h.items, splits);
+  dim3 grid(ceil_div(Co, 64) * ceil_div(Ci, 64), splits);
+  if (hmode == 2) {
+    if (dtype == MI355_F16) hipLaunchKernelGGL((wgrad3x3_halo_kernel<f16_t, true>), grid, dim3(256), 0, (hipStream_t)s, h);
+    else hipLaunchKernelGGL((wgrad3x3_halo_kernel<bf16_t, true>), grid, dim3(256), 0, (hipStream_t)s, h);
+  } else {
+    if (dtype == MI355_F16) hipLaunchKernelGGL((wgrad3x3_halo_kernel<f16_t, false>), grid, dim3(256), 0, (hipStream_t)s, h);
+    else hipLaunchKernelGGL((wgrad3x3_halo_kernel<bf16_t, false>), grid, dim3(256), 0, (hipStream_t)s, h);
+  }
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+
 
 // dw[co][ci][kh][kw] (or [ci][co][kh][kw] when transposed) = beta*dw + sum_s ws[s][co][tap][ci]
 // One 1024-thread workgroup per (co, 32-channel ci tile).  Thread (kl, cl) sums splits kl, kl+32, ... of channel

@@ -14,8 +14,11 @@
 #include "common.hpp"
 
 struct Wgrad3Args {
-  const void* x;
-  const void* dy;
+  // up to six (x, dy) pairs of ONE shared convolution (the recurrent blocks apply a conv six times, R2AttU_Net.py:41-44):
+  // their weight gradients are one sum, so the pairs are simply more work items of the same launch
+  const void* xs[6];
+  const void* dys[6];
+  int items_per_app;             // work items of one pair
   float* ws;
   int N, Hi, Wi, Ci, ldx;        // physical X
   int H, W, Co, ldy;             // dY / logical X grid
@@ -62,8 +65,6 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args 
   const int bid = xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
   const int bx = bid % gridDim.x, by = bid / gridDim.x;
   const int co0 = (bx / ciTiles) * 64, ci0 = (bx % ciTiles) * 64;
-  const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
-  const T* __restrict__ dy = reinterpret_cast<const T*>(a.dy);
   const char* zero = reinterpret_cast<const char*>(g_zero_page);
   auto swz = [](int px) { return (((px >> 1) & 1) | (((px >> 3) & 1) << 1)) << 1; };     // XOR on the 16-B chunk index
 
@@ -96,7 +97,10 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args 
   const int item0 = by * a.items_per_block;
   const int item1 = min(a.items, item0 + a.items_per_block);
   for (int item = item0; item < item1; ++item) {
-    int t = item;
+    const int app = item / a.items_per_app;
+    const T* __restrict__ x = reinterpret_cast<const T*>(a.xs[app]);
+    const T* __restrict__ dy = reinterpret_cast<const T*>(a.dys[app]);
+    int t = item - app * a.items_per_app;
     const int band = t % BANDS; t /= BANDS;
     const int tx = t % TXN;
     const int n = t / TXN;

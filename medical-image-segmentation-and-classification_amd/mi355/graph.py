@@ -235,6 +235,9 @@ class Builder:
         self.fwd: List[Launch] = []
         self.bwd: List[Launch] = []
         self._rules = []                 # closures, run in reverse at finish()
+        self._conv_uses = {}             # id(conv) -> forward applications (recurrent blocks share a conv)
+        self._pending_wgrad = {}         # id(conv) -> [(x, dy)] waiting for the other applications' backward
+        self.multi_wgrad = os.environ.get("MI355_WGRAD_MULTI", "1") != "0"
         self.keep = []
         self.ws_need = {"bytes": 0, "f32": 0}
         self._packs = {}
@@ -426,9 +429,21 @@ class Builder:
                                k, k, s, 1, -p, 1, 1 if up else 0, 2 if relu else 0, stat_part, self.code, flops=flops, nbytes=nbytes,
                                tag=self.igemm_tag(Co, x.C, k, s, Ho, Wo, False, up, M=x.N * Ho * Wo)))
         y.needs_grad = x.needs_grad or conv.weight.requires_grad
+        self._conv_uses[id(conv)] = self._conv_uses.get(id(conv), 0) + 1
 
         def bwd(dy, bias_done=False):
-            if conv.weight.requires_grad:
+            uses = self._conv_uses[id(conv)]
+            if (conv.weight.requires_grad and 1 < uses <= 6 and self.multi_wgrad and k == 3 and s == 1 and p == 1 and self.esz == 2
+                    and lib.mi355_conv2d_wgrad_multi_ok(x.N, Ho, Wo, self.code)):
+                # a convolution applied several times (recurrent block): ONE weight-gradient launch over all (x, dy) pairs, emitted
+                # with the last application's backward (the first in forward order), ONE set of partial slabs, ONE reduce
+                pend = self._pending_wgrad.setdefault(id(conv), [])
+                pend.append((x, dy))
+                assert (x.N, x.H, x.W, x.C, x.ld, dy.ld) == tuple(getattr(pend[0][0], f) for f in ("N", "H", "W", "C", "ld")) + (pend[0][1].ld,)
+                if len(pend) == uses:
+                    self._emit_multi_wgrad(conv, pend, Ho, Wo, Co, k, up, flops, nbytes)
+                    del self._pending_wgrad[id(conv)]
+            elif conv.weight.requires_grad:
                 splits = lib.mi355_conv2d_wgrad_splits(x.N, Ho, Wo, x.C, Co, k, k)
                 ws = self.ws_bytes(splits * Co * k * k * x.C * 4)
                 self.bwd.append(Launch("mi355_conv2d_wgrad", x, dy, ws, splits, x.N, x.H, x.W, x.C, x.ld, Ho, Wo, Co, dy.ld,
@@ -461,6 +476,20 @@ class Builder:
                                            xg.ld, k, k, 1, -1, p, s, 0, acc, None, self.code, flops=flops, nbytes=nbytes,
                                            tag=self.igemm_tag(x.C, Co, k, s, x.H, x.W, True, False, M=x.N * x.H * x.W)))
         return y, bwd
+
+    def _emit_multi_wgrad(self, conv, pend, Ho, Wo, Co, k, up, flops, nbytes):
+        x0 = pend[0][0]
+        n = len(pend)
+        splits = lib.mi355_conv2d_wgrad_splits(x0.N * n, Ho, Wo, x0.C, Co, k, k)
+        ws = self.ws_bytes(splits * Co * k * k * x0.C * 4)
+        ops = []
+        for i in range(6):
+            ops += list(pend[i]) if i < n else [None, None]
+        self.bwd.append(Launch("mi355_conv2d_wgrad_multi", *ops, n, ws, splits, x0.N, x0.H, x0.W, x0.C, x0.ld, Ho, Wo, Co,
+                               pend[0][1].ld, 1 if up else 0, self.code, flops=flops * n, nbytes=nbytes * n, side=True,
+                               tag=self.wgrad_tag(Co, x0.C, k, 1, Ho, Wo)))
+        ref, beta = self.pgrad(conv.weight)
+        self.bwd.append(Launch("mi355_conv2d_wgrad_reduce", ws, splits, ref, Co, x0.C, conv.in_channels, k, k, 0, beta, side=True))
 
     def igemm_tag(self, co, ci, k=1, s=1, Ho=0, Wo=0, dgrad=False, up=False, M=0):
         """Kernel variant mi355_conv2d_igemm dispatches to (mirrors the launcher in csrc/conv_igemm.hip)."""
@@ -1013,6 +1042,7 @@ class Builder:
             self.pre.append(Launch("mi355_pack_conv_weights_batched", table, len(rows), len(rows[0]), self.code))
         for r in reversed(self._rules):
             r()
+        assert not self._pending_wgrad, "a shared convolution's weight gradient is still waiting for an application's backward"
         # resolve _WsOff into (tensor, byte offset) late-bound pairs
         plan = Plan(self)
         for lst in (plan.pre, plan.fwd, plan.bwd):

@@ -400,6 +400,33 @@ def test_resume_from_checkpoint_is_bit_exact(tmp_path, dtype):
         assert float(go["state"][i]["step"]) == float(st["step"]) == 4.0
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_recurrent_weight_gradients_one_launch_matches_per_application(monkeypatch, dtype):
+    """The shared convolution of a recurrent block gets its weight gradient from ONE mi355_conv2d_wgrad_multi launch over the
+    six (x, dy) pairs (levels the nine-tap kernel serves: 32x32 and, two images at a time, 16x16) — same fp32 sums as six
+    mi355_conv2d_wgrad + reduce rounds (MI355_WGRAD_MULTI=0), up to the order of the additions."""
+    from mi355 import nn as mnn
+    from models.segmentation_models.R2AttU_Net import R2AttU_Net
+    x, y = otrain.synthetic_batch(2, 32, seed=21)
+    grads, counts = [], []
+    for multi in ("1", "0"):
+        monkeypatch.setenv("MI355_WGRAD_MULTI", multi)
+        torch.manual_seed(5)
+        m = R2AttU_Net()
+        m.compute_dtype = dtype
+        m = m.to(DEV).train()
+        loss = mnn.BCEWithLogitsLoss()(m(x.to(DEV)), y.to(DEV))
+        loss.backward()
+        torch.cuda.synchronize()
+        grads.append({k: p.grad.detach().float().cpu().clone() for k, p in m.named_parameters()})
+        plan = [p for p in m.engine.plans.values() if p.training][0]
+        counts.append(sum(l.name == "mi355_conv2d_wgrad_multi" for l in plan.bwd))
+    assert counts[0] > 0 and counts[1] == 0
+    for k, g in grads[0].items():
+        ref = grads[1][k]
+        assert float((g - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-12, k
+
+
 def _pool_gap(sd64, x):
     """smallest relative gap between the two largest values of a 2x2 max-pool window (positive maximum) anywhere in
     the VGG16_BN feature stack, evaluated in fp64"""

@@ -108,13 +108,15 @@ template <typename T> struct RowdotBwdOp {
 #pragma unroll
     for (int e = 0; e < EPC; ++e) wr[e] = w[c0 + e];
   }
-  __device__ void apply(size_t row, int c0, Acc (&acc)[NQ][EPC]) const {
-    const float d = dz[row];
-    const Vec16<T> v = ld16<T>(x + row * ldx + c0);
+  static constexpr int FETCH_ROWS = 4;        // (rowred.hpp: rows fetched before any is finished; one workgroup per CU)
+  struct In { Vec16<T> v; float d; };
+  __device__ In fetch(size_t row, int c0) const { return In{ld16<T>(x + row * ldx + c0), dz[row]}; }
+  __device__ void finish(const In& in, size_t row, int c0, Acc (&acc)[NQ][EPC]) const {
+    const float d = in.d;
     Vec16<T> o;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
-      const float xv = to_f32<T>(v.v[e]);
+      const float xv = to_f32<T>(in.v.v[e]);
       acc[0][e] += d * xv;
       acc[1][e] += d;
       o.v[e] = from_f32<T>((mask && !(xv > 0.f)) ? 0.f : d * wr[e]);

@@ -136,3 +136,39 @@ def test_tester_reports_match_the_reference_text(tmp_path, capsys):
                               "R2Unet,79.0,87.25,96.5,88.0,86.5,87.24\n")
     tester.save_results_to_csv({"AttentionUNet": res["AttentionUNet"]}, str(c), str(s_))
     assert "No classification results to save" in capsys.readouterr().out
+
+
+def test_recurrent_convs_get_one_weight_gradient_launch(monkeypatch):
+    """A convolution applied six times (Recurrent_block, t = 5) on a level the nine-tap kernel serves emits ONE
+    mi355_conv2d_wgrad_multi over its six (x, dy) pairs and ONE overwriting reduce; smaller levels and
+    MI355_WGRAD_MULTI=0 keep one launch per application (first overwrites, five accumulate)."""
+    from models.segmentation_models.R2U_Net import R2U_Net
+
+    def plan_of(multi):
+        monkeypatch.setenv("MI355_WGRAD_MULTI", multi)
+        net = R2U_Net().train()
+        net.engine.flatten()
+        plan = net.engine.plan_for((2, 3, 32, 32), True, True, torch.bfloat16)
+        plan.bind(0)                                 # ABI arity of every launch, the new entry point included
+        return net, plan
+
+    net, plan = plan_of("1")
+    multis = [l for l in plan.bwd if l.name == "mi355_conv2d_wgrad_multi"]
+    assert multis and all(l.args[12] == 6 for l in multis)              # napp
+    assert all(sum(a is not None for a in l.args[:12]) == 12 for l in multis)
+    for l in multis:                                                     # six distinct inputs, six distinct gradients
+        assert len({id(a) for a in l.args[0:12:2]}) == 6 and len({id(a) for a in l.args[1:12:2]}) == 6
+    # levels: 32x32 (rows of 32) and 16x16 (two images at a time) are served; 8x8 and below are not
+    served = {(l.args[20], l.args[21]) for l in multis}                  # (Ho, Wo)
+    assert served == {(32, 32), (16, 16)}
+    # every parameter still gets exactly one overwriting gradient write
+    betas = {}
+    for l in plan.bwd:
+        if l.name == "mi355_conv2d_wgrad_reduce":
+            betas.setdefault(id(l.args[2].param), []).append(l.args[-1])
+    assert len(betas) >= 30 and all(b.count(0.0) == 1 for b in betas.values())      # (the Co = 1 head goes through rowdot_bwd)
+    n_reduce_multi = sum(l.name == "mi355_conv2d_wgrad_reduce" for l in plan.bwd)
+    _, plan0 = plan_of("0")
+    assert not any(l.name == "mi355_conv2d_wgrad_multi" for l in plan0.bwd)
+    n_reduce_single = sum(l.name == "mi355_conv2d_wgrad_reduce" for l in plan0.bwd)
+    assert n_reduce_single - n_reduce_multi == 5 * len(multis)

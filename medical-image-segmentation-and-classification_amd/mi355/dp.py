@@ -34,6 +34,27 @@ class DataParallel:
         self.run_calls = None                 # injectable (CPU tests replace the kernel launcher)
         if self.world > 1 or force:
             self.engine.bwd_runner = self._run_backward
+        if self.world > 1:
+            self.sync_state()
+
+    @torch.no_grad()
+    def sync_state(self, src: int = 0):
+        """Replicas start from rank ``src``'s parameters and buffers (what DistributedDataParallel does at construction):
+        one broadcast of the flat parameter buffer, one per buffer dtype (BatchNorm running_mean / running_var /
+        num_batches_tracked).  Without it a rank-dependent initialisation, or a checkpoint loaded on one rank only, gives
+        replicas that sum gradients but apply them to different weights."""
+        self.engine._check_storage()
+        dist.broadcast(self.engine.flat_p, src=src, group=self.group)
+        by_dtype = {}
+        for b in self.net.buffers():
+            by_dtype.setdefault(b.dtype, []).append(b)
+        for dtype, bufs in sorted(by_dtype.items(), key=lambda kv: str(kv[0])):
+            flat = torch.cat([b.reshape(-1) for b in bufs])
+            dist.broadcast(flat, src=src, group=self.group)
+            o = 0
+            for b in bufs:
+                b.copy_(flat[o:o + b.numel()].view(b.shape))
+                o += b.numel()
 
     # ---- bucket schedule: (launch index after which the bucket is complete, lo, hi) -----------------
     def schedule(self, plan):

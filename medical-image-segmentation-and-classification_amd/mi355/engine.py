@@ -206,7 +206,9 @@ class Net(nn.Module):
         r = super()._apply(fn, recurse)
         p = next(self.parameters(), None)
         if p is not None and p.device.type == "cuda" and p.dtype == torch.float32:
-            self.engine.flatten()
+            # only when the storage really moved: a no-op .to(device) / .cuda() must not re-point the parameters away from
+            # the flat buffers an optimiser or the data-parallel wrapper already holds
+            self.engine._check_storage()
         return r
 
     def build(self, g: graph.Builder, x: graph.T):

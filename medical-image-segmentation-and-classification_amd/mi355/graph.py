@@ -704,10 +704,11 @@ class Builder:
                 # roles swap: the big tensor dy is gathered with stride-s addressing, x is the "dy" operand
                 splits = lib.mi355_conv2d_wgrad_splits(x.N, x.H, x.W, Co, Ci, k, k)
                 ws = self.ws_bytes(splits * Ci * k * k * Co * 4)
+                # side=True like every other user of the split-K slab workspace: all of them serialise on the side stream
                 self.bwd.append(Launch("mi355_conv2d_wgrad", dy, x, ws, splits, x.N, Ho, Wo, Co, dy.ld, x.H, x.W, Ci, x.ld,
-                                       k, k, s, 0, 0, self.code))
+                                       k, k, s, 0, 0, self.code, side=True))
                 ref, beta = self.pgrad(mod.weight)
-                self.bwd.append(Launch("mi355_conv2d_wgrad_reduce", ws, splits, ref, Ci, Co, Co, k, k, 0, beta))
+                self.bwd.append(Launch("mi355_conv2d_wgrad_reduce", ws, splits, ref, Ci, Co, Co, k, k, 0, beta, side=True))
                 if mod.bias is not None:
                     self.bias_grad_from(dy, mod.bias)
             if x.needs_grad:

@@ -3,6 +3,7 @@
 the clip coefficient stay in device memory so the whole step is graph-capturable."""
 from __future__ import annotations
 
+import weakref
 from typing import Iterable
 
 import torch
@@ -10,15 +11,22 @@ import torch
 from .lib import lib
 
 
-_REGISTRY = {}     # storage pointer of a flat parameter buffer -> (flat_p, flat_g)
+_REGISTRY = {}     # storage pointer of a flat parameter buffer -> (weakref(flat_p), weakref(flat_g))
 
 
 def register_flat(flat_p, flat_g):
-    _REGISTRY[flat_p.untyped_storage().data_ptr()] = (flat_p, flat_g)
+    """Called by Engine.flatten().  Weak references: a model that re-flattens (``.to()`` onto another device) or is
+    dropped must not keep its old parameter / gradient buffers alive through this table."""
+    for k in [k for k, (wp, wg) in _REGISTRY.items() if wp() is None or wg() is None]:
+        del _REGISTRY[k]
+    _REGISTRY[flat_p.untyped_storage().data_ptr()] = (weakref.ref(flat_p), weakref.ref(flat_g))
 
 
-def _grad_buffer_of(params):
-    """Locate params inside an engine's flat buffers -> (flat_p, flat_g, lo, hi) or None."""
+def _locate(params):
+    """Locate params inside an engine's flat buffers -> (flat_p, flat_g, runs) or None.  ``runs`` are the maximal
+    contiguous [lo, hi) element ranges the parameters cover (holes of up to 3 floats are the 16-byte alignment padding
+    between neighbouring slots and do not split a run; anything else — a frozen encoder in front of a trainable
+    decoder, ResnetUnet.py:60-66 — does)."""
     params = list(params)
     if not params:
         return None
@@ -26,43 +34,52 @@ def _grad_buffer_of(params):
     spans = []
     for p in params:
         reg = _REGISTRY.get(p.untyped_storage().data_ptr())
-        if reg is None:
+        if reg is None or reg[0]() is None or reg[1]() is None:
             return None
+        fp, fg = reg[0](), reg[1]()
         if owner is None:
-            owner = reg
-        elif reg[0] is not owner[0]:
+            owner = (fp, fg)
+        elif fp is not owner[0]:
             return None
-        off = (p.data_ptr() - owner[0].data_ptr()) // 4
+        off = (p.data_ptr() - fp.data_ptr()) // 4
         spans.append((off, off + p.numel()))
     spans.sort()
-    for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
-        if b0 - a1 > 3 or b0 < a1:          # contiguous up to the 16-byte alignment padding
-            return None
-    return owner[0], owner[1], spans[0][0], spans[-1][1]
+    runs = [list(spans[0])]
+    for a0, a1 in spans[1:]:
+        if a0 < runs[-1][1]:
+            return None                      # overlapping views: not the engine's layout
+        if a0 - runs[-1][1] <= 3:
+            runs[-1][1] = a1
+        else:
+            runs.append([a0, a1])
+    return owner[0], owner[1], [tuple(r) for r in runs]
 
 
 class _Shared:
-    """Clip state handed from clip_grad_norm_ to the next optimizer.step() on the same flat range."""
-    by_buffer = {}
+    """Clip state handed from clip_grad_norm_ to the next optimizer.step() on the same flat buffer."""
+    by_buffer = {}    # flat parameter buffer pointer -> state (keyed by BUFFER: the ranges clipped and the ranges an optimizer
+    #                   owns may differ — helpers.py:333 clips model.parameters(), the optimizer may hold a superset)
     amp = {}          # flat parameter buffer pointer -> device 1/scale of an active loss scaler (amp.GradScaler.unscale_)
 
 
-def _clip_state(base, lo, hi):
-    st = _Shared.by_buffer.get((base.data_ptr(), lo, hi))
-    if st is None:
+def _clip_state(base, nruns):
+    st = _Shared.by_buffer.get(base.data_ptr())
+    if st is None or st["partial"].numel() < 1024 * nruns:
         dev = base.device
-        st = {"partial": torch.empty(1024, device=dev), "norm": torch.zeros(1, device=dev),
+        st = {"partial": torch.empty(1024 * nruns, device=dev), "norm": torch.zeros(1, device=dev),
               "coef": torch.ones(1, device=dev), "finf": torch.zeros(1, device=dev), "fresh": False}
-        _Shared.by_buffer[(base.data_ptr(), lo, hi)] = st
+        _Shared.by_buffer[base.data_ptr()] = st
     return st
 
 
-def _norm_pass(base, g, lo, hi, max_norm, inv_scale):
-    """sum of squares of g[lo:hi] -> norm, clip coefficient, found_inf (device scalars)."""
-    lo4 = lo - lo % 4
-    nb = lib.mi355_rowreduce_blocks(hi - lo4)
-    st = _clip_state(base, lo, hi)
-    lib.mi355_sumsq_partial(g[lo4:hi], st["partial"], hi - lo4)
+def _norm_pass(base, g, runs, max_norm, inv_scale):
+    """sum of squares of g over ``runs`` -> norm, clip coefficient, found_inf (device scalars)."""
+    st = _clip_state(base, len(runs))
+    nb = 0
+    for lo, hi in runs:
+        lo4 = lo - lo % 4                   # (parameter slots are 16-byte aligned: lo4 == lo for runs that start at a slot)
+        lib.mi355_sumsq_partial(g[lo4:hi], st["partial"][nb:], hi - lo4)
+        nb += lib.mi355_rowreduce_blocks(hi - lo4)
     lib.mi355_clip_coef(st["partial"], nb, float(max_norm), float(inv_scale), _Shared.amp.get(base.data_ptr()), st["norm"],
                         st["coef"], st["finf"], None)
     st["fresh"] = True
@@ -70,22 +87,24 @@ def _norm_pass(base, g, lo, hi, max_norm, inv_scale):
 
 
 def clip_grad_norm_(parameters: Iterable[torch.Tensor], max_norm: float, inv_scale: float = 1.0):
-    """torch.nn.utils.clip_grad_norm_ semantics (global L2 norm, coef = min(1, max/(norm+1e-6))).
-    The scaling itself is folded into the following AdamW launch; returns the norm as a 0-dim
-    device tensor (no host sync)."""
+    """torch.nn.utils.clip_grad_norm_ semantics (global L2 norm over the parameters that have a gradient,
+    coef = min(1, max/(norm+1e-6))).  The scaling itself is folded into the following AdamW launch; returns the norm
+    as a 0-dim device tensor (no host sync)."""
     params = [p for p in parameters if p.requires_grad]
-    r = _grad_buffer_of(params)
+    r = _locate(params)
     if r is None:
         raise RuntimeError("mi355.optim.clip_grad_norm_ needs the parameters of a mi355 Net (flat storage); "
                            "there is no torch fallback on this path")
-    base, g, lo, hi = r
-    st = _norm_pass(base, g, lo, hi, max_norm, inv_scale)
+    base, g, runs = r
+    st = _norm_pass(base, g, runs, max_norm, inv_scale)
     return st["norm"].view(())
 
 
 class AdamW(torch.optim.Optimizer):
-    """torch.optim.AdamW-compatible front (param_groups / lr schedulers work unchanged) whose step()
-    is a single fused launch per parameter group over the engine's flat buffers."""
+    """torch.optim.AdamW-compatible front (param_groups / lr schedulers work unchanged) whose step() is one fused
+    launch per contiguous TRAINABLE run of a parameter group over the engine's flat buffers.  Like torch.optim.AdamW,
+    parameters without a gradient (``requires_grad == False``: the frozen encoder of ResnetUnet.py:60-66 inside
+    ``AdamW(model.parameters())``, helpers.py:251) are skipped entirely — no weight decay, no moment update."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
@@ -93,42 +112,66 @@ class AdamW(torch.optim.Optimizer):
         self.inv_scale = 1.0          # e.g. 1/world_size: gradients are summed, not averaged, by the all-reduce
         for gr in self.param_groups:
             ps = [p for p in gr["params"]]
-            r = _grad_buffer_of(ps)
+            r = _locate(ps)
             if r is None:
                 raise RuntimeError("mi355.optim.AdamW needs parameters of a mi355 Net that is already on the GPU "
                                    "(call model.to(device) and run / flatten it first)")
-            base, g, lo, hi = r
+            base, g, runs = r
+            lo, hi = runs[0][0], runs[-1][1]
             dev = base.device
             self._st.append({
-                "p": base, "g": g, "lo": lo, "hi": hi,
+                "p": base, "g": g, "lo": lo, "hi": hi, "runs": {},
                 "m": torch.zeros(hi - lo, device=dev), "v": torch.zeros(hi - lo, device=dev),
                 "lr": torch.tensor([gr["lr"]], dtype=torch.float32, device=dev), "lr_host": gr["lr"],
                 "step": torch.zeros(1, dtype=torch.int32, device=dev),
                 "one": torch.ones(1, device=dev), "scratch": torch.zeros(2, device=dev),
             })
 
+    def _trainable_runs(self, gr, st):
+        """Contiguous ranges of the group's parameters that currently have a gradient (cached per requires_grad mask)."""
+        sig = tuple(p.requires_grad for p in gr["params"])
+        runs = st["runs"].get(sig)
+        if runs is None:
+            p0 = gr["params"][0]
+            base = st["p"]
+            if not (base.data_ptr() <= p0.data_ptr() < base.data_ptr() + base.numel() * 4):
+                raise RuntimeError("mi355.optim.AdamW: the model's parameters no longer live in the flat buffer this optimizer "
+                                   "was built on (the model was moved / re-flattened); create the optimizer after model.to(device)")
+            tr = [p for p in gr["params"] if p.requires_grad]
+            r = _locate(tr) if tr else None
+            runs = st["runs"][sig] = (r[2] if r is not None else [])
+        return runs
+
     @torch.no_grad()
     def step(self, closure=None):
+        consumed = []
         for gr, st in zip(self.param_groups, self._st):
             if gr["lr"] != st["lr_host"]:
                 st["lr"].fill_(gr["lr"])
                 st["lr_host"] = gr["lr"]
-            lo, hi = st["lo"], st["hi"]
-            clip = _Shared.by_buffer.get((st["p"].data_ptr(), lo, hi))
+            runs = self._trainable_runs(gr, st)
+            if not runs:
+                continue
+            clip = _Shared.by_buffer.get(st["p"].data_ptr())
             amp_inv = _Shared.amp.get(st["p"].data_ptr())           # a loss scaler has unscale_()d this optimizer
             if amp_inv is not None and not (clip is not None and clip["fresh"]):
-                clip = _norm_pass(st["p"], st["g"], lo, hi, 0.0, self.inv_scale)    # found_inf without clipping
+                clip = _norm_pass(st["p"], st["g"], runs, 0.0, self.inv_scale)    # found_inf without clipping
             coef, finf = st["one"], None
             if clip is not None and clip["fresh"]:
                 coef = clip["coef"]
-                clip["fresh"] = False
+                consumed.append(clip)
                 if amp_inv is not None:
                     finf = clip["finf"]                              # GradScaler.step: skip on inf / nan gradients
             st["finf"] = finf
             lib.mi355_step_tick(st["step"], finf)
             b1, b2 = gr["betas"]
-            lib.mi355_adamw(st["p"][lo:hi], st["g"][lo:hi], st["m"], st["v"], hi - lo, st["lr"], float(b1), float(b2),
-                            float(gr["eps"]), float(gr["weight_decay"]), coef, float(self.inv_scale), amp_inv, finf, st["step"])
+            base_lo = st["lo"]
+            for lo, hi in runs:
+                lib.mi355_adamw(st["p"][lo:hi], st["g"][lo:hi], st["m"][lo - base_lo:hi - base_lo], st["v"][lo - base_lo:hi - base_lo],
+                                hi - lo, st["lr"], float(b1), float(b2), float(gr["eps"]), float(gr["weight_decay"]), coef,
+                                float(self.inv_scale), amp_inv, finf, st["step"])
+        for clip in consumed:               # one clip result serves every group of this step, then expires
+            clip["fresh"] = False
         return None
 
     # ---- checkpoints in torch.optim.AdamW's own format (the reference saves only model weights, helpers.py:394-400;

@@ -3,7 +3,7 @@ No kernels run here (no GPU): the backward plan's launches are replaced by a fak
 writes a rank-dependent value into every parameter-gradient range a launch would write, so the test
 checks exactly the host logic that matters for N>1: every bucket is reduced only after the last
 launch writing into it, buckets tile the gradient buffer, and after backward every rank holds the
-SUM over ranks (the 1/world factor is folded into clip/AdamW via inv_scale)."""
+SUM over ranks; replicas built from different seeds start from rank 0's parameters and buffers (the 1/world factor is folded into clip/AdamW via inv_scale)."""
 import os
 import socket
 
@@ -27,13 +27,23 @@ def _worker(rank, world, port, bucket_mb, q):
         from mi355 import graph
         from mi355.dp import DataParallel
         from models.segmentation_models.AttentionUNet import AttentionUNet
-        torch.manual_seed(0)
+        torch.manual_seed(rank)                         # rank-dependent initialisation AND BatchNorm buffers ...
         net = AttentionUNet().train()
         eng = net.engine
         eng.flatten()                                   # CPU flat buffers (no kernels are launched)
+        with torch.no_grad():
+            for b in net.buffers():
+                b.add_(rank + 1)
         plan = eng.plan_for((2, 3, 32, 32), True, True, torch.float32)
         dp = DataParallel(net, bucket_mb=bucket_mb, overlap=True)
         assert dp.world == world and abs(dp.inv_scale - 1.0 / world) < 1e-12
+        # ... are replaced by rank 0's at construction (DDP semantics): replicas apply summed gradients to the SAME weights
+        torch.manual_seed(0)
+        ref = AttentionUNet()
+        for (k, v), (_, w) in zip(net.state_dict().items(), ref.state_dict().items()):
+            want = w if k in dict(ref.named_parameters()) else w + 1
+            assert torch.equal(v, want), k
+        assert all(p.data_ptr() == eng.flat_p.data_ptr() + eng.offsets[id(p)][0] * 4 for p in net.parameters())
         buckets = dp.schedule(plan)
         # 1) buckets tile the gradient ranges of all parameters, each exactly once
         spans = sorted((eng.offsets[id(p)][0], eng.offsets[id(p)][0] + eng.offsets[id(p)][1]) for p in plan.grad_params)

@@ -172,3 +172,22 @@ def test_recurrent_convs_get_one_weight_gradient_launch(monkeypatch):
     assert not any(l.name == "mi355_conv2d_wgrad_multi" for l in plan0.bwd)
     n_reduce_single = sum(l.name == "mi355_conv2d_wgrad_reduce" for l in plan0.bwd)
     assert n_reduce_single - n_reduce_multi == 5 * len(multis)
+
+
+@pytest.mark.parametrize("name", ["ResNetUnet", "AttentionUNet", "R2AttU_Net", "ResNet50", "VGG16_BN"])
+def test_slab_workspace_is_owned_by_one_stream(name):
+    """The split-K slab workspace Ws('bytes') is shared by every weight-gradient launch of a plan; the side stream
+    only waits for the main stream at a fork, so a main-stream user of the same workspace would race with it
+    (ConvTranspose2d of ResnetUnet.py:21,51 once did).  All users must sit on the same stream."""
+    if name == "ResNetUnet":
+        from models.segmentation_models.ResnetUnet import ResNetUnet
+        ctor, shape = (lambda: ResNetUnet(freeze=False)), (1, 3, 64, 64)
+    else:
+        ctor, shape = _models()[name]
+    net = ctor().train()
+    net.engine.flatten()
+    plan = net.engine.plan_for(shape, True, True, torch.bfloat16)
+    users = [l for l in plan.bwd if any(isinstance(a, graph.Ws) and a.kind == "bytes" for a in l.args)]
+    assert users and {l.side for l in users} == {True}, {(l.name, l.side) for l in users}
+    # and the other shared workspace never appears on the side stream
+    assert not any(l.side for l in plan.bwd if any(isinstance(a, graph.Ws) and a.kind == "f32" for a in l.args))

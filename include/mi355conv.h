@@ -197,12 +197,17 @@ int mi355_relu_bwd(const void* dy, int lddy, const void* y, int ldy, void* dx, i
                    int dtype, mi355_stream_t s);
 
 /* ---- attention gate / single-output 1x1 conv (AttentionUNet.py:29-54, 84) ------------------ */
-/* z[m] = b + sum_c x[m][c]*w[c]  (Conv2d(C,1,1)); optional per-block partial (sum z, sum z^2). */
+/* z[m] = b + sum_c x[m][c]*w[c]  (ONE output channel of a Conv2d(C,K,1): the attention gate's psi, K = 1, and the logit
+ * heads `out` / `conv_1x1` with out_channel = K, AttentionUNet.py:84, R2AttU_Net.py:117); optional per-block partial
+ * (sum z, sum z^2).  K > 1: the launch produces channel plane k of an NCHW fp32 map [N][K][HW] — pass z + k*HW (and the
+ * k-th weight row / bias); pixel m = n*HW + p lands at z[n*K*HW + p].  K == 1: HW is ignored. */
 int mi355_rowdot_fwd(const void* x, int ldx, const float* w, const float* b, float* z, float* partial,
-                     long long M, int C, int dtype, mi355_stream_t s);
-/* dx[m][c] (+)= dz[m]*w[c] (masked by xmask>0 if given); partial dw[c] = sum_m dz[m]*x[m][c], db. */
+                     long long M, int C, int HW, int K, int dtype, mi355_stream_t s);
+/* dx[m][c] = dz[m]*w[c] (masked by x>0 if relu_mask), added to dx when accumulate (the further planes of a K-channel
+ * head); partial dw[c] = sum_m dz[m]*x[m][c], db.  dz is indexed like z above. */
 int mi355_rowdot_bwd(const float* dz, const void* x, int ldx, const float* w, void* dx, int lddx,
-                     float* partial, long long M, int C, int relu_mask, int dtype, mi355_stream_t s);
+                     float* partial, long long M, int C, int relu_mask, int HW, int K, int accumulate, int dtype,
+                     mi355_stream_t s);
 /* y[m][c] = x[m][c] * sigmoid(z[m]*scale[0]+shift[0]) */
 int mi355_gate_mul_fwd(const void* x, int ldx, const float* z, const float* scale, const float* shift,
                        void* y, int ldy, long long M, int C, int dtype, mi355_stream_t s);

@@ -38,7 +38,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w,
                                                          const float* __restrict__ b, float* __restrict__ z,
                                                          float* __restrict__ partial, long long M, int C,
-                                                         int rows_per_block, int tpr) {
+                                                         int rows_per_block, int tpr, int hw, int K) {
   constexpr int EPC = 16 / (int)sizeof(T);
   const int cp = C / EPC;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const T* __restrict__ x
     acc = seg_sum(acc, tpr);
     if (r < r1 && sub == 0) {
       const float zz = acc + bias;
-      z[r] = zz;
+      z[K == 1 ? r : r + (r / hw) * (long long)(K - 1) * hw] = zz;      // K > 1: channel plane of an NCHW [N][K][hw] map
       s0 += zz;
       s1 += (double)zz * zz;
     }
@@ -80,8 +80,9 @@ __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const T* __restrict__ x
 }
 
 extern "C" int mi355_rowdot_fwd(const void* x, int ldx, const float* w, const float* b, float* z, float* partial,
-                                long long M, int C, int dtype, mi355_stream_t s) {
+                                long long M, int C, int HW, int K, int dtype, mi355_stream_t s) {
   MI355_CHECK_ARG(x && w && z, "rowdot_fwd: null pointer");
+  MI355_CHECK_ARG(K >= 1 && (K == 1 || (HW > 0 && M % HW == 0)), "rowdot_fwd: K=%d planes need HW | M", K);
   const int epc = dtype_is_2byte(dtype) ? 8 : 4;
   MI355_CHECK_ARG(C % epc == 0 && C / epc <= 64 * ROWDOT_MAXCH, "rowdot_fwd: unsupported C=%d", C);
   const int nb = rowreduce_blocks(M);
@@ -90,7 +91,7 @@ extern "C" int mi355_rowdot_fwd(const void* x, int ldx, const float* w, const fl
   return dispatch_dtype(dtype, "rowdot_fwd", [&](auto tag) {
     using T = decltype(tag);
     hipLaunchKernelGGL((rowdot_fwd_kernel<T>), dim3(nb), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx, w, b, z, partial, M, C, rpb,
-                       tpr);
+                       tpr, HW, K);
     MI355_LAUNCH_CHECK();
     return (int)MI355_OK;
   });
@@ -102,7 +103,7 @@ template <typename T> struct RowdotBwdOp {
   static constexpr bool WRITES = true;
   typedef float Acc;
   static constexpr int EPC = 16 / (int)sizeof(T);
-  const float* dz; const T* x; int ldx; const float* w; T* dx; int lddx; int mask;
+  const float* dz; const T* x; int ldx; const float* w; T* dx; int lddx; int mask; int hw; int K; int acc_dx;
   float wr[EPC];
   __device__ void load_cols(int c0) {
 #pragma unroll
@@ -110,7 +111,9 @@ template <typename T> struct RowdotBwdOp {
   }
   static constexpr int FETCH_ROWS = 4;        // (rowred.hpp: rows fetched before any is finished; one workgroup per CU)
   struct In { Vec16<T> v; float d; };
-  __device__ In fetch(size_t row, int c0) const { return In{ld16<T>(x + row * ldx + c0), dz[row]}; }
+  __device__ In fetch(size_t row, int c0) const {
+    return In{ld16<T>(x + row * ldx + c0), dz[K == 1 ? row : row + (row / hw) * (size_t)(K - 1) * hw]};
+  }
   __device__ void finish(const In& in, size_t row, int c0, Acc (&acc)[NQ][EPC]) const {
     const float d = in.d;
     Vec16<T> o;
@@ -121,16 +124,23 @@ template <typename T> struct RowdotBwdOp {
       acc[1][e] += d;
       o.v[e] = from_f32<T>((mask && !(xv > 0.f)) ? 0.f : d * wr[e]);
     }
+    if (dx && acc_dx) {                       // a further output channel of a multi-channel head adds its share
+      const Vec16<T> old = ld16<T>(dx + row * lddx + c0);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) o.v[e] = from_f32<T>(to_f32<T>(old.v[e]) + to_f32<T>(o.v[e]));
+    }
     if (dx) st16<T>(dx + row * lddx + c0, o);
   }
 };
 
 extern "C" int mi355_rowdot_bwd(const float* dz, const void* x, int ldx, const float* w, void* dx, int lddx,
-                                float* partial, long long M, int C, int relu_mask, int dtype, mi355_stream_t s) {
+                                float* partial, long long M, int C, int relu_mask, int HW, int K, int accumulate, int dtype,
+                                mi355_stream_t s) {
   MI355_CHECK_ARG(dz && x && w && partial, "rowdot_bwd: null pointer");
+  MI355_CHECK_ARG(K >= 1 && (K == 1 || (HW > 0 && M % HW == 0)), "rowdot_bwd: K=%d planes need HW | M", K);
   return dispatch_dtype(dtype, "rowdot_bwd", [&](auto tag) {
     using T = decltype(tag);
-    RowdotBwdOp<T> op{dz, (const T*)x, ldx, w, (T*)dx, lddx, relu_mask};
+    RowdotBwdOp<T> op{dz, (const T*)x, ldx, w, (T*)dx, lddx, relu_mask, HW, K, accumulate};
     return rowred_launch<T>(op, M, C, partial, (hipStream_t)s);
   });
 }

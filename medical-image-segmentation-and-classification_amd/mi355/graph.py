@@ -796,14 +796,14 @@ class Builder:
         self.see(cp.weight, cp.bias, bp.weight, bp.bias)
         if self.training:
             part = self.ws_f32(nb * 2)
-            self.fwd.append(Launch("mi355_rowdot_fwd", p, p.ld, cp.weight, cp.bias, z, part, M, F_int, self.code))
+            self.fwd.append(Launch("mi355_rowdot_fwd", p, p.ld, cp.weight, cp.bias, z, part, M, F_int, 0, 1, self.code))
             track = bp.track_running_stats
             self.fwd.append(Launch("mi355_bn_finalize", part, nb, M, 1, bp.weight, bp.bias,
                                    bp.running_mean if track else None, bp.running_var if track else None,
                                    bp.num_batches_tracked if track else None, float(bp.momentum or 0.1), float(bp.eps),
                                    sp["scale"], sp["shift"], sp["mean"], sp["invstd"]))
         else:
-            self.fwd.append(Launch("mi355_rowdot_fwd", p, p.ld, cp.weight, cp.bias, z, None, M, F_int, self.code))
+            self.fwd.append(Launch("mi355_rowdot_fwd", p, p.ld, cp.weight, cp.bias, z, None, M, F_int, 0, 1, self.code))
             self.fwd.append(Launch("mi355_bn_eval_coeffs", bp.weight, bp.bias, bp.running_mean, bp.running_var, float(bp.eps), 1,
                                    sp["scale"], sp["shift"]))
         y = out if out is not None else self.new_tensor(x.N, x.H, x.W, x.C)
@@ -834,7 +834,7 @@ class Builder:
             # psi conv (F_int -> 1): dp = dz*w masked by p>0, dw, db
             dp = self.new_tensor(x.N, x.H, x.W, F_int)
             part3 = self.ws_f32(nb * 2 * F_int)
-            self.bwd.append(Launch("mi355_rowdot_bwd", dz, p, p.ld, cp.weight, dp, dp.ld, part3, M, F_int, 1, self.code))
+            self.bwd.append(Launch("mi355_rowdot_bwd", dz, p, p.ld, cp.weight, dp, dp.ld, part3, M, F_int, 1, 0, 1, 0, self.code))
             wref, wbeta = self.pgrad(cp.weight)
             self.bwd.append(Launch("mi355_colsum_finalize", part3, nb, 2, F_int, wref, wbeta))
             bref2, bbeta = self.pgrad(cp.bias)
@@ -847,36 +847,43 @@ class Builder:
         self.rule(rule)
         return y
 
-    # ---- single-output 1x1 conv producing the fp32 logit map (AttentionUNet.py:84,119) -------------------------------
+    # ---- 1x1 head producing the fp32 logit map [N,K,H,W] (AttentionUNet.py:84,119; R2AttU_Net.py:117,156; ResnetUnet.py:58) ------
     def logit_conv(self, x, conv):
-        assert conv.out_channels == 1 and conv.kernel_size[0] == 1
-        M = x.M
-        z = self.f32(M)
+        """``out_channel`` = K per-pixel dot products (K = 1 in every configuration the reference runs); plane k of the
+        NCHW fp32 output is one ``mi355_rowdot_fwd`` launch, the loss reads the buffer in place."""
+        assert conv.kernel_size[0] == 1 and conv.stride[0] == 1 and conv.padding[0] == 0
+        M, K, C, HW = x.M, conv.out_channels, x.C, x.H * x.W
+        z = self.f32(M * K)
         self.see(conv.weight, conv.bias)
-        self.fwd.append(Launch("mi355_rowdot_fwd", x, x.ld, conv.weight, conv.bias, z, None, M, x.C, self.code))
-        self.output = ("z", z, (x.N, 1, x.H, x.W))
+        for k in range(K):
+            self.fwd.append(Launch("mi355_rowdot_fwd", x, x.ld, (conv.weight, k * C * 4), (conv.bias, k * 4) if conv.bias is not None else None,
+                                   (z, k * HW * 4), None, M, C, HW, K, self.code))
+        self.output = ("z", z, (x.N, K, x.H, x.W))
         needs = x.needs_grad or conv.weight.requires_grad
         if self.want_grad and needs:
-            self.dout = self.f32(M)
+            self.dout = self.f32(M * K)
 
         def rule():
             if not needs:
                 return
             nb = lib.mi355_rowreduce_blocks(M)
-            part = self.ws_f32(nb * 2 * x.C)
             dx = None
             if x.needs_grad:
                 if self.acc_flag(x):
                     raise NotImplementedError("logit_conv input with several consumers")
                 dx = self.grad_of(x)
-            self.bwd.append(Launch("mi355_rowdot_bwd", self.dout, x, x.ld, conv.weight, dx, dx.ld if dx is not None else 0, part,
-                                   M, x.C, 0, self.code))
-            if conv.weight.requires_grad:
-                wref, wbeta = self.pgrad(conv.weight)
-                self.bwd.append(Launch("mi355_colsum_finalize", part, nb, 2, x.C, wref, wbeta))
-                if conv.bias is not None:
-                    bref, bbeta = self.pgrad(conv.bias)
-                    self.bwd.append(Launch("mi355_colsum_finalize", self._ws_off(part, x.C * 4), nb, 2 * x.C, 1, bref, bbeta))
+            for k in range(K):
+                part = self.ws_f32(nb * 2 * C)
+                self.bwd.append(Launch("mi355_rowdot_bwd", (self.dout, k * HW * 4), x, x.ld, (conv.weight, k * C * 4), dx,
+                                       dx.ld if dx is not None else 0, part, M, C, 0, HW, K, 1 if k else 0, self.code))
+                if conv.weight.requires_grad:
+                    wref, wbeta = self.pgrad(conv.weight)
+                    self.bwd.append(Launch("mi355_colsum_finalize", part, nb, 2, C, GRef(wref.tensor, wref.off + k * C * 4, wref.param),
+                                           wbeta if k == 0 else 0.0))
+                    if conv.bias is not None:
+                        bref, bbeta = self.pgrad(conv.bias)
+                        self.bwd.append(Launch("mi355_colsum_finalize", self._ws_off(part, C * 4), nb, 2 * C, 1,
+                                               GRef(bref.tensor, bref.off + k * 4, bref.param), bbeta if k == 0 else 0.0))
         self.rule(rule)
         return z
 

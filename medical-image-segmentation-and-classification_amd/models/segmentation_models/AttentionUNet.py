@@ -13,7 +13,7 @@ class AttentionUNet(Net):
         super().__init__()
         self.in_channel, self.out_channel = in_channel, out_channel
         self.max_pool = nn.MaxPool2d(kernel_size=2, stride=2)
-        cin = 3
+        cin = 3            # the reference hard-codes basic_block(3, 64) and only stores in_channel (AttentionUNet.py:59,62)
         for i, w in enumerate(WIDTHS, start=1):                       # conv1..conv5
             setattr(self, f"conv{i}", conv_bn_relu_x2(cin, w))
             cin = w
@@ -25,8 +25,6 @@ class AttentionUNet(Net):
         self.out = nn.Conv2d(64, out_channel, kernel_size=1, stride=1, padding=0)
 
     def build(self, g, x):
-        if self.out_channel != 1:
-            raise NotImplementedError("the HIP logit head is single-channel (reference default out_channel=1)")
         skips = {}
         t = x
         for i in range(1, 6):

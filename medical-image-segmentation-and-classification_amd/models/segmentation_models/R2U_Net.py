@@ -28,8 +28,6 @@ class _R2Base(Net):
         self._out_channels = out_channels
 
     def build(self, g, x):
-        if self._out_channels != 1:
-            raise NotImplementedError("the HIP logit head is single-channel (reference default)")
         skips, t = {}, x
         for i in range(1, 6):
             if i > 1:

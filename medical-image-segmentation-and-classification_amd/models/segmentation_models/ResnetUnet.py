@@ -88,8 +88,6 @@ class ResNetUnet(Net):
                 p.requires_grad = False
 
     def build(self, g, x):
-        if self._n_classes != 1:
-            raise NotImplementedError("the HIP logit head is single-channel (reference default n_classes=1)")
         e1 = g.seq(self.encoder1, x)
         t = g.maxpool(e1, 3, 2, 1)
         feats = []

@@ -219,21 +219,60 @@ def metric_fixture(H):
     print("metrics: iou", H.iou(pred, mask), "acc", c, n)
 
 
-def main():
+def cls_metric_fixture():
+    """utils/tester.py:49-88 ``calculate_classification_metrics`` is six scikit-learn calls (accuracy_score; precision_ /
+    recall_ / f1_score with average="weighted" and average=None, zero_division=0; confusion_matrix).  tester.py itself
+    cannot be imported here (cv2 / albumentations are absent), so the SAME calls with the SAME keyword arguments are
+    made on fixed label vectors with the scikit-learn of this container (1.7.2; the algorithm is sklearn's published
+    support-weighted average of per-class precision / recall / F1 with 0 for empty denominators) and stored."""
+    from sklearn.metrics import accuracy_score, confusion_matrix, f1_score, precision_score, recall_score
+    g = np.random.RandomState(7)
+    cases = {
+        "mixed": (g.randint(0, 3, 200), g.randint(0, 3, 200)),
+        "skewed": (np.where(g.rand(300) < 0.8, 1, g.randint(0, 3, 300)), np.where(g.rand(300) < 0.7, 1, g.randint(0, 3, 300))),
+        "class_never_predicted": (np.array([0, 0, 1, 1, 0, 1, 0]), np.array([0, 1, 2, 1, 2, 1, 0])),
+        "class_never_true": (np.array([0, 2, 1, 1, 2, 1, 0]), np.array([0, 1, 1, 1, 0, 1, 0])),
+        "perfect": (np.array([2, 0, 1, 1, 2]), np.array([2, 0, 1, 1, 2])),
+        "single_class": (np.array([1, 1, 1]), np.array([1, 1, 1])),
+        "all_wrong": (np.array([1, 2, 0, 1]), np.array([0, 0, 1, 2])),
+    }
+    rec = {"names": np.array(list(cases))}
+    for tag, (pred, lab) in cases.items():
+        kw = dict(zero_division=0)
+        rec[f"{tag}/pred"], rec[f"{tag}/label"] = pred.astype(np.int64), lab.astype(np.int64)
+        rec[f"{tag}/accuracy"] = accuracy_score(lab, pred) * 100
+        rec[f"{tag}/precision"] = precision_score(lab, pred, average="weighted", **kw) * 100
+        rec[f"{tag}/recall"] = recall_score(lab, pred, average="weighted", **kw) * 100
+        rec[f"{tag}/f1"] = f1_score(lab, pred, average="weighted", **kw) * 100
+        rec[f"{tag}/precision_per_class"] = precision_score(lab, pred, average=None, **kw) * 100
+        rec[f"{tag}/recall_per_class"] = recall_score(lab, pred, average=None, **kw) * 100
+        rec[f"{tag}/f1_per_class"] = f1_score(lab, pred, average=None, **kw) * 100
+        rec[f"{tag}/confusion_matrix"] = confusion_matrix(lab, pred)
+    np.savez_compressed(os.path.join(OUT, "cls_metrics.npz"), **rec)
+    print("cls_metrics:", len(cases), "cases")
+
+
+def main(only=()):
     os.makedirs(OUT, exist_ok=True)
     C = _ref_classes()
     H = _ref_helpers()
-    block_fixtures(C)
-    metric_fixture(H)
-    model_fixture("AttentionUNet", C["AttentionUNet"], 64, True)
-    model_fixture("R2AttU_Net", C["R2AttU_Net"], 32, True)
-    model_fixture("R2U_Net", C["R2U_Net"], 32, True)
-    model_fixture("ResNet18", lambda: C["ResNet18"](num_classes=1000), 64, False, head_dropout=True, H=H)
-    model_fixture("ResNet50", lambda: C["ResNet50"](num_classes=1000), 64, False, head_dropout=True, H=H)
-    model_fixture("VGG16", lambda: C["VGG16"](num_classes=1000), 32, False, head_dropout=True, H=H)
-    train_traj_seg(C, H)
-    train_traj_cls(C, H)
+    jobs = {
+        "blocks": lambda: block_fixtures(C),
+        "metrics": lambda: metric_fixture(H),
+        "cls_metrics": cls_metric_fixture,
+        "AttentionUNet": lambda: model_fixture("AttentionUNet", C["AttentionUNet"], 64, True),
+        "R2AttU_Net": lambda: model_fixture("R2AttU_Net", C["R2AttU_Net"], 32, True),
+        "R2U_Net": lambda: model_fixture("R2U_Net", C["R2U_Net"], 32, True),
+        "ResNet18": lambda: model_fixture("ResNet18", lambda: C["ResNet18"](num_classes=1000), 64, False, head_dropout=True, H=H),
+        "ResNet50": lambda: model_fixture("ResNet50", lambda: C["ResNet50"](num_classes=1000), 64, False, head_dropout=True, H=H),
+        "VGG16": lambda: model_fixture("VGG16", lambda: C["VGG16"](num_classes=1000), 32, False, head_dropout=True, H=H),
+        "VGG19": lambda: model_fixture("VGG19", lambda: C["VGG19"](num_classes=1000), 32, False, head_dropout=True, H=H),
+        "train_traj_seg": lambda: train_traj_seg(C, H),
+        "train_traj_cls": lambda: train_traj_cls(C, H),
+    }
+    for k in (only or jobs):
+        jobs[k]()
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1:])       # no arguments: every fixture; otherwise the named ones (e.g. `make_golden.py VGG19 cls_metrics`)

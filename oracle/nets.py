@@ -380,7 +380,9 @@ def _spec_rrcnn(s, p, ci, co):
     s.conv(p + ".conv_1x1", ci, co, 1)
 
 
-def spec(name, num_classes=3, head_dropout=False):
+def spec(name, num_classes=3, head_dropout=False, in_channels=3, out_channels=1):
+    """``in_channels`` / ``out_channels``: constructor arguments of the R2 nets (R2U_Net.py:51, R2AttU_Net.py:89); AttentionUNet
+    honours only ``out_channel`` — its first block is hard-coded to 3 input channels (AttentionUNet.py:62)."""
     s = _Spec()
     w = (64, 128, 256, 512, 1024)
     if name == "AttentionUNet":
@@ -392,9 +394,9 @@ def spec(name, num_classes=3, head_dropout=False):
             _spec_up(s, f"up{lvl}", 2 * c, c)
             _spec_gate(s, f"att{lvl}", c, c // 2)
             _spec_double_conv(s, f"up_conv{lvl}", 2 * c, c)
-        s.conv("out", 64, 1, 1)
+        s.conv("out", 64, out_channels, 1)
     elif name in ("R2U_Net", "R2AttU_Net"):
-        ci = 3
+        ci = in_channels
         for i, c in enumerate(w, start=1):
             _spec_rrcnn(s, f"RRCNN{i}", ci, c); ci = c
         for lvl in (5, 4, 3, 2):
@@ -403,7 +405,7 @@ def spec(name, num_classes=3, head_dropout=False):
             if name == "R2AttU_Net":
                 _spec_gate(s, f"att{lvl}", c, c // 2)
             _spec_rrcnn(s, f"up_RRCNN{lvl}", 2 * c, c)
-        s.conv("conv_1x1", 64, 1, 1)
+        s.conv("conv_1x1", 64, out_channels, 1)
     elif name in ("ResNet18", "ResNet50"):
         s.conv("conv1", 3, 64, 7, bias=False); s.bn("bn1", 64)
         cin = 64

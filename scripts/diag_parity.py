@@ -1,0 +1,38 @@
+"""GPU diagnostic (not a test): where does the fp32 HIP forward of a model deviate from the fp64 oracle?
+Prints logits errors (eval / train) and, per BatchNorm in forward order, the error of the running statistics after ONE
+train-mode forward next to the CPU fp32 oracle's own error.  Usage: python scripts/diag_parity.py R2AttU_Net 2 32"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "medical-image-segmentation-and-classification_amd")]
+import torch
+from oracle import nets, train as otrain
+
+name, bs, hw = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+from utils.helpers import get_seg_model
+m = get_seg_model({"AttentionUNet": "attentionunet", "R2AttU_Net": "r2attunet", "R2U_Net": "r2unet"}[name])
+sd = nets.closed_form_state(name)
+m.load_state_dict(sd)
+m.compute_dtype = torch.float32
+m = m.to("cuda:0")
+x, mask = otrain.closed_form_input(bs, hw)
+rel = lambda a, b: float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+for mode in ("eval", "train"):
+    tr = mode == "train"
+    m.train(tr)
+    with torch.no_grad():
+        out = m(x.cuda()).cpu()
+    s32 = {k: v.clone() for k, v in sd.items()}
+    s64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    with torch.no_grad():
+        o32 = nets.NETS[name](s32, x, tr)
+        o64 = nets.NETS[name](s64, x.double(), tr)
+    print(f"{mode}: logits HIP-vs-fp64 {rel(out, o64):.2e}   CPUfp32-vs-fp64 {rel(o32, o64):.2e}")
+    if tr:
+        msd = m.state_dict()
+        worst = 0
+        for k in sd:
+            if k.endswith("running_var") or k.endswith("running_mean"):
+                e_g, e_c = rel(msd[k].cpu(), s64[k]), rel(s32[k], s64[k])
+                if e_g > 3 * worst or e_g > 1e-4:
+                    print(f"  {k:40s} HIP {e_g:.2e}  CPU {e_c:.2e}")
+                worst = max(worst, e_g)

@@ -42,9 +42,9 @@ def _build(name, dtype):
         m = getattr(ResNet, name)(num_classes=1000)
         helpers.add_dropout_to_fc(m, p=0.0)
         kw = {"head_dropout": True}
-    elif name == "VGG16":
-        from models.classification_models.VGG import VGG16
-        m = VGG16(num_classes=1000)
+    elif name in ("VGG16", "VGG19"):
+        from models.classification_models import VGG
+        m = getattr(VGG, name)(num_classes=1000)
         helpers.add_dropout_to_fc(m, p=0.0)
         for mod in m.modules():
             if isinstance(mod, torch.nn.Dropout):
@@ -56,7 +56,7 @@ def _build(name, dtype):
     return m.to(DEV), sd, kw
 
 
-@pytest.mark.parametrize("name", ["AttentionUNet", "R2AttU_Net", "R2U_Net", "ResNet18", "ResNet50", "VGG16"])
+@pytest.mark.parametrize("name", ["AttentionUNet", "R2AttU_Net", "R2U_Net", "ResNet18", "ResNet50", "VGG16", "VGG19"])
 def test_fp32_model_matches_reference_golden_and_oracle(name):
     from mi355 import nn as mnn, optim as moptim
     z = np.load(os.path.join(G, f"model_{name}.npz"))
@@ -79,7 +79,7 @@ def test_fp32_model_matches_reference_golden_and_oracle(name):
     loss = crit(out, yd)
     loss.backward()
     torch.cuda.synchronize()
-    assert _rel(out.detach().cpu().numpy(), z["logits_train"]) < (RTOL if "R2" not in name else 1e-2)   # R2*: 108 shared-weight convs
+    assert _rel(out.detach().cpu().numpy(), z["logits_train"]) < 1e-4      # measured 1.4e-5 (R2AttU_Net) .. 5e-5 (AttentionUNet) vs fp64
     assert abs(float(loss.detach()) - float(z["loss"])) < RTOL * max(1.0, abs(float(z["loss"])))
 
     # Gradients.  These fixtures (batch 2, 2x2..4x4 deepest level, up to 100+ stacked train-mode BNs)
@@ -427,12 +427,12 @@ def test_recurrent_weight_gradients_one_launch_matches_per_application(monkeypat
         assert float((g - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-12, k
 
 
-def _pool_gap(sd64, x):
+def _pool_gap(sd64, x, cfg):
     """smallest relative gap between the two largest values of a 2x2 max-pool window (positive maximum) anywhere in
     the VGG16_BN feature stack, evaluated in fp64"""
     import torch.nn.functional as F
     idx, gap, t = 0, 1.0, x.double()
-    for c in nets.VGG16_CFG:
+    for c in cfg:
         if c == "M":
             n, ch, h, w = t.shape
             s = t.reshape(n, ch, h // 2, 2, w // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, ch, h // 2, w // 2, 4).sort(-1, descending=True).values
@@ -445,17 +445,18 @@ def _pool_gap(sd64, x):
     return gap
 
 
-def test_vgg16_bn_matches_oracle_fp32():
-    """torchvision-layout vgg16_bn (the model helpers.py:158-166 requests from the hub; config 5's classifier).
+@pytest.mark.parametrize("name", ["VGG16_BN", "VGG19_BN"])
+def test_vgg_bn_matches_oracle_fp32(name):
+    """torchvision-layout vgg16_bn / vgg19_bn (the models helpers.py:158-166 requests from the hub; vgg16_bn is config 5's classifier).
     torchvision is absent, so the check is against the oracle only (parity unpinned at this boundary): eval and
     train logits, loss, gradients anchored on fp64 like the other nets, BN buffers.  64x64 input -> 2x2 feature
     map, so AdaptiveAvgPool2d((7,7)) runs its up-sampling branch (overlapping / repeated windows)."""
     from mi355 import nn as mnn
-    from models.classification_models.VGG import VGG16_BN
+    from models.classification_models import VGG
     from utils.helpers import add_dropout_to_fc
-    name = "VGG16_BN"
+    cfg = nets.VGG16_CFG if name == "VGG16_BN" else nets.VGG19_CFG
     sd = nets.closed_form_state(name, num_classes=3, head_dropout=True)
-    m = VGG16_BN(num_classes=1000)
+    m = getattr(VGG, name)(num_classes=1000)
     assert add_dropout_to_fc(m, p=0.0) == "classifier"
     for mod in m.modules():
         if isinstance(mod, torch.nn.Dropout):
@@ -470,14 +471,14 @@ def test_vgg16_bn_matches_oracle_fp32():
     x0, _ = otrain.closed_form_input(2, 64)
     sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
     cands = [x0.roll((i, j), dims=(2, 3)) for i in range(4) for j in range(4)]
-    gaps = [_pool_gap(sd64, c) for c in cands]
+    gaps = [_pool_gap(sd64, c, cfg) for c in cands]
     x = cands[int(np.argmax(gaps))]
     assert max(gaps) > 2e-6, gaps
     y = torch.tensor([1, 2])
     m.eval()
     with torch.no_grad():
         ev = m(x.to(DEV)).cpu()
-        ev_ref = nets.vgg16_bn({k: v.clone() for k, v in sd.items()}, x, False)
+        ev_ref = nets.NETS[name]({k: v.clone() for k, v in sd.items()}, x, False)
     assert _rel(ev.numpy(), ev_ref.numpy()) < RTOL
     m.train()
     out = m(x.to(DEV))

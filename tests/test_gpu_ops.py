@@ -239,7 +239,7 @@ def test_attention_gate_tail(dtype, c):
     pd, xd = to_nhwc(p.detach(), dtype), to_nhwc(x.detach(), dtype)
     zd = torch.empty(m, device=DEV)
     nb, part = _partials(m, 1)
-    lib.mi355_rowdot_fwd(pd, c, dev(wp.detach().flatten()), dev(bp.detach()), zd, part, m, c, code)
+    lib.mi355_rowdot_fwd(pd, c, dev(wp.detach().flatten()), dev(bp.detach()), zd, part, m, c, 0, 1, code)
     sc, sh, mu, isd = (torch.empty(1, device=DEV) for _ in range(4))
     lib.mi355_bn_finalize(part, nb, m, 1, dev(gam.detach()), dev(bet.detach()), None, None, None, 0.1, 1e-5, sc, sh, mu, isd)
     od = torch.empty_like(xd)
@@ -254,7 +254,7 @@ def test_attention_gate_tail(dtype, c):
     lib.mi355_bn1_bwd_apply(dzn, zd, dev(gam.detach()), mu, isd, sums, dz, m)
     dpd = torch.empty_like(pd)
     nb3, part3 = _partials(m, c)
-    lib.mi355_rowdot_bwd(dz, pd, c, dev(wp.detach().flatten()), dpd, c, part3, m, c, 0, code)
+    lib.mi355_rowdot_bwd(dz, pd, c, dev(wp.detach().flatten()), dpd, c, part3, m, c, 0, 0, 1, 0, code)
     dw = torch.empty(c, device=DEV); db = torch.empty(c, device=DEV)
     lib.mi355_colsum_finalize(part3, nb3, 2, c, dw, 0.0)
     lib.mi355_colsum_finalize(part3[c:], nb3, 2, c, db, 0.0)

@@ -54,7 +54,7 @@ def test_frozen_encoder_clip_and_adamw_match_oracle():
         s[k].requires_grad_(False)
     raw = {k: g.clone() for k, g in grads.items()}
     ref_total = otrain.clip_grad_norm(list(grads.values()), 1.0)
-    assert ref_total > 2.0, "fixture must make the clip active"
+    assert ref_total > 1.1, "fixture must make the clip active (coef = 1/norm < 0.91)"
     oopt = otrain.AdamW(trainable, lr)
     with torch.no_grad():
         oopt.step(s, grads)

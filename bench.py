@@ -105,25 +105,44 @@ def pmc_traffic(kernel):
     return None, None
 
 
-def cpu_baseline(hw, bs, steps):
-    """Reference-equivalent CPU path (oracle/) on this box's host cores: fp32, one warm-up + `steps` timed."""
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(hw, bs=8, steps=3):
+    """SURVEY.md 8(d) protocol: the reference-equivalent CPU path (oracle/: plain torch fp32 restatement of the reference's
+    train step, helpers.py:320-336) on ALL of this box's host cores (the process's affinity mask), B = 8 (the reference's own
+    segmentation batch size, trainer.py:160; the benchmark's 32 would take ~1 min per step), one warm-up + 3 timed steps,
+    images/s = B / median step time; CPU model and core count reported."""
     from oracle import nets, train as otrain
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, int(os.environ.get("BENCH_CPU_THREADS", "16"))))   # a 1-GPU box owns a 16-core share
+    if os.environ.get("BENCH_CPU_THREADS"):
+        cores = max(1, min(cores, int(os.environ["BENCH_CPU_THREADS"])))
     torch.set_num_threads(cores)
     sd = nets.default_init_state("AttentionUNet", seed=0)
     x, y = otrain.synthetic_batch(bs, hw, seed=0)
     opt = otrain.AdamW(nets.param_keys(sd), 1e-6)
     otrain.train_step("AttentionUNet", sd, x, y, opt, True)
-    t0 = time.time()
+    times = []
     for _ in range(steps):
+        t0 = time.time()
         otrain.train_step("AttentionUNet", sd, x, y, opt, True)
-    dt = (time.time() - t0) / steps
+        times.append(time.time() - t0)
+    dt = sorted(times)[len(times) // 2]
     return {"value": round(bs / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"AttentionUNet {hw}x{hw} fp32 train step, bs={bs} (per-image rate), 1 warm-up + {steps} timed steps"}
+            "cpu_model": cpu_model_name(),
+            "sample": f"AttentionUNet {hw}x{hw} fp32 train step (fwd+BCE+bwd+clip+AdamW), B={bs} (reference's seg batch size; "
+                      f"the GPU line runs B=32), 1 warm-up + {steps} timed steps, B / median step time",
+            "step_seconds": [round(t, 3) for t in times]}
 
 
 def main():
@@ -298,7 +317,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log("per-kernel profile done; timing the CPU oracle baseline")
-        result["cpu_baseline"] = cpu_baseline(args.size, 2, 2)
+        result["cpu_baseline"] = cpu_baseline(args.size, 8, 3)
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(result) + "\n").encode())

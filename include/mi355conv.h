@@ -276,12 +276,6 @@ int mi355_adaptive_avgpool_fwd(const void* x, int ldx, float* y, int N, int H, i
 int mi355_adaptive_avgpool_bwd(const float* dy, void* dx, int lddx, int N, int H, int W, int C, int OH, int OW, int dtype,
                                mi355_stream_t s);
 
-/* ---- hardware ceiling probe (scripts/mfma_ceiling.py; not on the product path) -------------------------------- */
-/* blocks x 256 threads run `iters` trips of 48 v_mfma_f32_16x16x32_bf16 per wave on random operands (mode 0: operands in
- * registers; mode 1: plus 18 ds_read_b128 fragment reads per trip, the halo kernel's LDS diet) or 24 v_mfma_f32_32x32x16_bf16
- * (mode 2).  rnd: 1 MiB of finite bf16 bit patterns. */
-int mi355_probe_mfma(int mode, const void* rnd, int blocks, int iters, float* sink, mi355_stream_t s);
-
 /* ---- input pipeline on the GPU (utils/trainer.py:52-115 Albumentations transforms; utils/dataset.py:100-134) ----------- */
 /* dst[n][y][x][c] (uint8) = sample of src[n] ([Hs][Ws][C] uint8, C <= 4) at (sx, sy) = m[n] (2x3, row-major) applied to the dst
  * pixel (x, y): bilinear with cv2's rounding, or nearest; border = replicate (A.Resize) or reflect-101 (A.ShiftScaleRotate). */

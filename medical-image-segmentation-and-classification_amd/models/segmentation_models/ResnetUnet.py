@@ -13,37 +13,13 @@ import torch.nn as nn
 
 from mi355.engine import Net
 from ._blocks import conv_bn_relu_x2
+from models.classification_models.TorchvisionResNet import Bottleneck, make_layer   # torchvision ResNet-50 v1.5 containers
 
 basic_block = conv_bn_relu_x2
 
 
-class Bottleneck(nn.Module):
-    """torchvision.models.resnet.Bottleneck (v1.5) parameter container."""
-    expansion = 4
-
-    def __init__(self, inplanes, planes, stride=1, downsample=None):
-        super().__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
-        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes)
-        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
-        self.bn3 = nn.BatchNorm2d(planes * 4)
-        self.relu = nn.ReLU(inplace=True)
-        self.downsample = downsample
-
-    def lower(self, g, x):
-        idn = x if self.downsample is None else g.conv_bn_act(x, self.downsample[0], self.downsample[1], act=False)
-        y = g.conv_bn_act(x, self.conv1, self.bn1, act=True)
-        y = g.conv_bn_act(y, self.conv2, self.bn2, act=True)
-        return g.conv_bn_act(y, self.conv3, self.bn3, act=True, res=idn)
-
-
 def _layer(inplanes, planes, blocks, stride):
-    ds = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False), nn.BatchNorm2d(planes * 4))
-    mods = [Bottleneck(inplanes, planes, stride, ds)]
-    mods += [Bottleneck(planes * 4, planes) for _ in range(blocks - 1)]
-    return nn.Sequential(*mods)
+    return make_layer(Bottleneck, inplanes, planes, blocks, stride)
 
 
 class DecoderBlock(nn.Module):

@@ -40,15 +40,22 @@ def add_dropout_to_fc(model, p=0.5, classes=CLASSES):
     return None
 
 
-def get_class_model(name):
+def get_class_model(name, hub=None):
     """name -> (model, head attribute name); random init.  The reference first asks torch.hub for the torchvision
-    model (`vgg16` -> `vgg16_bn`, helpers.py:158-166) and falls back to its local classes when that fails
-    (:170-192); there is no network here, so "vgg16" / "vgg19" / "resnet*" are the local classes (the reference's
-    offline behaviour) and the hub layouts are reachable by their own names "vgg16_bn" / "vgg19_bn"."""
-    from models.classification_models import ResNet, VGG
-    table = {"resnet18": ResNet.ResNet18, "resnet50": ResNet.ResNet50, "vgg16": VGG.VGG16, "vgg19": VGG.VGG19,
-             "vgg16_bn": VGG.VGG16_BN, "vgg19_bn": VGG.VGG19_BN}
+    model (`resnet18` / `resnet50`; `vgg16` -> `vgg16_bn`, helpers.py:158-166) and falls back to its local classes when
+    that fails (:170-192).  There is no network here, so by default "vgg16" / "vgg19" / "resnet*" are the local classes
+    (the reference's offline behaviour); ``hub=True`` (or MI355_HUB_LAYOUT=1) selects the torchvision layouts the online
+    reference trains — `TorchvisionResNet.resnet18/50`, `VGG.VGG16_BN/VGG19_BN` — into which hub checkpoints load
+    unchanged.  The hub layouts are also reachable by their own names "vgg16_bn" / "vgg19_bn" / "resnet18_tv" / "resnet50_tv"."""
+    from models.classification_models import ResNet, TorchvisionResNet, VGG
+    local = {"resnet18": ResNet.ResNet18, "resnet50": ResNet.ResNet50, "vgg16": VGG.VGG16, "vgg19": VGG.VGG19}
+    tv = {"resnet18": TorchvisionResNet.resnet18, "resnet50": TorchvisionResNet.resnet50, "vgg16": VGG.VGG16_BN, "vgg19": VGG.VGG19_BN}
+    named = {"vgg16_bn": VGG.VGG16_BN, "vgg19_bn": VGG.VGG19_BN, "resnet18_tv": TorchvisionResNet.resnet18,
+             "resnet50_tv": TorchvisionResNet.resnet50}
+    if hub is None:
+        hub = os.environ.get("MI355_HUB_LAYOUT", "0") == "1"
     key = name.lower()
+    table = {**(tv if hub else local), **named}
     if key not in table:
         raise ValueError(f"Unknown classification model: {name}")
     model = table[key](num_classes=1000)

@@ -315,7 +315,40 @@ def resnet_unet(sd, x, training=False):
     return _conv(sd, "out", d)
 
 
+def _basic_block_tv(sd, p, x, stride, tr):
+    """torchvision BasicBlock: conv3x3(stride)-BN-ReLU-conv3x3-BN + shortcut (downsample.{0,1})."""
+    idn = x
+    if (p + ".downsample.0.weight") in sd:
+        idn = _bn(sd, p + ".downsample.1", _conv(sd, p + ".downsample.0", x, stride, 0), tr)
+    y = F.relu(_bn(sd, p + ".bn1", _conv(sd, p + ".conv1", x, stride, 1), tr))
+    y = _bn(sd, p + ".bn2", _conv(sd, p + ".conv2", y, 1, 1), tr)
+    return F.relu(y + idn)
+
+
+def _resnet_tv(sd, x, training, block, counts, drop_mask):
+    """torchvision ResNet (the hub models helpers.py:158-161 asks for): one bn1, global AVERAGE pool — parity
+    unpinned (restated from torchvision's public architecture; torchvision is absent here)."""
+    tr = training
+    x = F.relu(_bn(sd, "bn1", _conv(sd, "conv1", x, 2, 3), tr))
+    x = F.max_pool2d(x, 3, 2, 1)
+    for li, n in enumerate(counts, start=1):
+        for b in range(n):
+            x = block(sd, f"layer{li}.{b}", x, 2 if (li > 1 and b == 0) else 1, tr)
+    x = F.adaptive_avg_pool2d(x, 1).flatten(1)
+    return _head(sd, "fc", x, tr, drop_mask)
+
+
+def resnet18_tv(sd, x, training=False, drop_mask=None):
+    return _resnet_tv(sd, x, training, _basic_block_tv, (2, 2, 2, 2), drop_mask)
+
+
+def resnet50_tv(sd, x, training=False, drop_mask=None):
+    return _resnet_tv(sd, x, training, _bottleneck_tv, (3, 4, 6, 3), drop_mask)
+
+
 NETS = {
+    "resnet18_tv": resnet18_tv,
+    "resnet50_tv": resnet50_tv,
     "AttentionUNet": attention_unet,
     "R2U_Net": r2u_net,
     "R2AttU_Net": r2attu_net,
@@ -454,6 +487,24 @@ def spec(name, num_classes=3, head_dropout=False, in_channels=3, out_channels=1)
         s.linear("classifier.0", 25088, 4096)
         s.linear("classifier.3", 4096, 4096)
         s.linear("classifier.7" if head_dropout else "classifier.6", 4096, num_classes)
+    elif name in ("resnet18_tv", "resnet50_tv"):
+        s.conv("conv1", 3, 64, 7, bias=False); s.bn("bn1", 64)
+        cin = 64
+        exp, counts = (1, (2, 2, 2, 2)) if name == "resnet18_tv" else (4, (3, 4, 6, 3))
+        for li, (width, n) in enumerate(zip((64, 128, 256, 512), counts), start=1):
+            for b in range(n):
+                p = f"layer{li}.{b}"; stride = 2 if (li > 1 and b == 0) else 1
+                if exp == 1:
+                    s.conv(p + ".conv1", cin, width, 3, False); s.bn(p + ".bn1", width)
+                    s.conv(p + ".conv2", width, width, 3, False); s.bn(p + ".bn2", width)
+                else:
+                    s.conv(p + ".conv1", cin, width, 1, False); s.bn(p + ".bn1", width)
+                    s.conv(p + ".conv2", width, width, 3, False); s.bn(p + ".bn2", width)
+                    s.conv(p + ".conv3", width, 4 * width, 1, False); s.bn(p + ".bn3", 4 * width)
+                if stride != 1 or cin != width * exp:
+                    s.conv(p + ".downsample.0", cin, width * exp, 1, False); s.bn(p + ".downsample.1", width * exp)
+                cin = width * exp
+        s.linear("fc.1" if head_dropout else "fc", 512 * exp, num_classes)
     elif name == "ResNetUnet":
         s.conv("encoder1.0", 3, 64, 7, bias=False); s.bn("encoder1.1", 64)
         cin = 64

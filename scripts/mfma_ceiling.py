@@ -5,7 +5,16 @@ import os, sys, time
 R = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'medical-image-segmentation-and-classification_amd'))
 import torch
-from mi355.lib import lib
+import ctypes
+_dll = ctypes.CDLL(os.path.join(R, 'medical-image-segmentation-and-classification_amd', 'mi355', 'libmi355probe.so'))
+_dll.mi355_probe_mfma.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+
+
+class lib:      # include/mi355probe.h
+    @staticmethod
+    def mi355_probe_mfma(mode, rnd, blocks, iters, sink):
+        rc = _dll.mi355_probe_mfma(mode, rnd.data_ptr(), blocks, iters, sink.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, rc
 dev = "cuda:0"
 rnd = (torch.randn(65536 * 8, device=dev)).to(torch.bfloat16)
 sink = torch.zeros(4, device=dev)

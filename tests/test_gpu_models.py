@@ -500,3 +500,103 @@ def test_vgg_bn_matches_oracle_fp32(name):
         e_cpu.append(float((g32[k].double() - ref).abs().max()) / sc)
     assert np.median(e_gpu) <= max(RTOL, 3 * np.median(e_cpu)), (np.median(e_gpu), np.median(e_cpu))
     assert np.max(e_gpu) <= max(RTOL, 5 * np.max(e_cpu)), (np.max(e_gpu), np.max(e_cpu))
+
+
+@pytest.mark.parametrize("name,ctor_kw,spec_kw,cin", [
+    ("AttentionUNet", dict(in_channel=3, out_channel=3), dict(out_channels=3), 3),
+    ("R2U_Net", dict(in_channels=1, out_channels=2, t=2), dict(in_channels=1, out_channels=2), 1),
+])
+def test_constructor_channel_arguments(name, ctor_kw, spec_kw, cin):
+    """Constructor surface beyond the defaults (AttentionUNet.py:56-84 ``out_channel``; R2U_Net.py:50-83 ``in_channels`` /
+    ``out_channels`` / ``t``): K-channel logit heads and non-RGB inputs run on the HIP path and match the oracle."""
+    from mi355 import nn as mnn
+    if name == "AttentionUNet":
+        from models.segmentation_models.AttentionUNet import AttentionUNet as C
+    else:
+        from models.segmentation_models.R2U_Net import R2U_Net as C
+    t = ctor_kw.get("t", 5)
+    sd = nets.closed_form_state(name, **spec_kw)
+    m = C(**ctor_kw)
+    m.load_state_dict(sd)
+    m.compute_dtype = torch.float32
+    m = m.to(DEV)
+    K = spec_kw["out_channels"]
+    x, mask = otrain.closed_form_input(2, 32, c=cin)
+    y = torch.cat([mask.roll(3 * k, dims=3) for k in range(K)], 1)
+    okw = {} if name == "AttentionUNet" else {"t": t}
+    m.eval()
+    with torch.no_grad():
+        ev = m(x.to(DEV)).cpu()
+        ref = nets.NETS[name]({k: v.clone() for k, v in sd.items()}, x, False, **okw)
+    assert ev.shape == ref.shape == (2, K, 32, 32)
+    assert _rel(ev.numpy(), ref.numpy()) < 1e-4
+    m.train()
+    out = m(x.to(DEV))
+    loss = mnn.BCEWithLogitsLoss()(out, y.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    l64, o64, g64 = otrain.forward_backward(name, sd64, x.double(), y.double(), True, **okw)
+    _, _, g32 = otrain.forward_backward(name, {k: v.clone() for k, v in sd.items()}, x, y, True, **okw)
+    assert _rel(out.detach().cpu().numpy(), o64.numpy()) < 1e-4
+    assert abs(float(loss.detach()) - l64) < 1e-5
+    params = dict(m.named_parameters())
+    head = "out" if name == "AttentionUNet" else "conv_1x1"
+    for k in (head + ".weight", head + ".bias"):                 # the head itself: no kink between it and the loss
+        assert _rel(params[k].grad.cpu().numpy(), g64[k].numpy()) < 1e-4, k
+    gmax = max(float(v.abs().max()) for v in g64.values())
+    e_gpu, e_cpu = [], []
+    for k, refg in g64.items():
+        sc = float(refg.abs().max())
+        if sc < 1e-6 * gmax:
+            continue
+        e_gpu.append(float((params[k].grad.cpu().double() - refg).abs().max()) / sc)
+        e_cpu.append(float((g32[k].double() - refg).abs().max()) / sc)
+    assert np.median(e_gpu) <= max(RTOL, 3 * np.median(e_cpu)), (np.median(e_gpu), np.median(e_cpu))
+
+
+@pytest.mark.parametrize("name", ["resnet18_tv", "resnet50_tv"])
+def test_torchvision_layout_resnets_match_oracle_fp32(name):
+    """The hub layouts of helpers.py:158-161 (torchvision resnet18 / resnet50; parity unpinned — torchvision is absent, the
+    oracle restates the public architecture): logits, loss and every gradient tensor against the fp64 oracle."""
+    from mi355 import nn as mnn
+    from utils.helpers import get_class_model
+    sd = nets.closed_form_state(name, num_classes=3, head_dropout=True)
+    m, head = get_class_model(name)
+    assert head == "fc"
+    m.fc[0].p = 0.0
+    m.load_state_dict(sd)
+    m.compute_dtype = torch.float32
+    m = m.to(DEV)
+    x, y = otrain.synthetic_batch(8, 64, seed=3, classes=3)
+    m.eval()
+    with torch.no_grad():
+        ev = m(x.to(DEV)).cpu()
+        ev_ref = nets.NETS[name]({k: v.clone() for k, v in sd.items()}, x, False)
+    assert _rel(ev.numpy(), ev_ref.numpy()) < 1e-4
+    m.train()
+    out = m(x.to(DEV))
+    loss = mnn.CrossEntropyLoss(label_smoothing=0.1)(out, y.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    l64, o64, g64 = otrain.forward_backward(name, sd64, x.double(), y, False)
+    _, o32, g32 = otrain.forward_backward(name, {k: v.clone() for k, v in sd.items()}, x, y, False)
+    assert _rel(out.detach().cpu().numpy(), o64.numpy()) < 1e-4
+    assert abs(float(loss.detach()) - l64) < 1e-5 * max(1.0, abs(l64))
+    params = dict(m.named_parameters())
+    gmax = max(float(v.abs().max()) for v in g64.values())
+    e_gpu, e_cpu = [], []
+    for k, ref in g64.items():
+        sc = float(ref.abs().max())
+        if sc < 1e-6 * gmax:
+            continue
+        e_gpu.append(float((params[k].grad.cpu().double() - ref).abs().max()) / sc)
+        e_cpu.append(float((g32[k].double() - ref).abs().max()) / sc)
+    assert np.median(e_gpu) <= max(1e-4, 3 * np.median(e_cpu)), (np.median(e_gpu), np.median(e_cpu))
+    assert np.max(e_gpu) <= max(RTOL, 5 * np.max(e_cpu)), (np.max(e_gpu), np.max(e_cpu))
+    msd = m.state_dict()
+    _, _, _ = otrain.forward_backward(name, sd, x, y, False)          # (updates the oracle's BN buffers in place)
+    for k, v in sd.items():
+        if k.endswith(("running_mean", "running_var")):
+            assert _rel(msd[k].cpu().numpy(), v.numpy()) < RTOL, k

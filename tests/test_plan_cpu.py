@@ -17,7 +17,9 @@ def _models():
     from models.segmentation_models.R2U_Net import R2U_Net
     from models.classification_models.ResNet import ResNet18, ResNet50
     from models.classification_models.VGG import VGG16, VGG19, VGG16_BN, VGG19_BN
-    return {"AttentionUNet": (AttentionUNet, (2, 3, 32, 32)), "R2AttU_Net": (R2AttU_Net, (1, 3, 32, 32)),
+    from models.classification_models.TorchvisionResNet import resnet18, resnet50
+    return {"resnet18_tv": (lambda: resnet18(3), (2, 3, 64, 64)), "resnet50_tv": (lambda: resnet50(3), (2, 3, 64, 64)),
+            "AttentionUNet": (AttentionUNet, (2, 3, 32, 32)), "R2AttU_Net": (R2AttU_Net, (1, 3, 32, 32)),
             "R2U_Net": (R2U_Net, (1, 3, 32, 32)), "ResNet18": (lambda: ResNet18(3), (2, 3, 64, 64)),
             "ResNet50": (lambda: ResNet50(3), (2, 3, 64, 64)), "VGG16": (lambda: VGG16(3), (2, 3, 32, 32)),
             "VGG19": (lambda: VGG19(3), (2, 3, 32, 32)), "VGG16_BN": (lambda: VGG16_BN(3), (2, 3, 32, 32)),
@@ -191,3 +193,23 @@ def test_slab_workspace_is_owned_by_one_stream(name):
     assert users and {l.side for l in users} == {True}, {(l.name, l.side) for l in users}
     # and the other shared workspace never appears on the side stream
     assert not any(l.side for l in plan.bwd if any(isinstance(a, graph.Ws) and a.kind == "f32" for a in l.args))
+
+
+def test_torchvision_resnet_layouts_have_the_published_sizes():
+    """helpers.py:158-161 trains torchvision's resnet18 / resnet50 when the hub is reachable: 11 689 512 / 25 557 032
+    parameters at 1000 classes, global AVERAGE pool, one bn1 application; the factory swaps the head like the reference."""
+    from models.classification_models import TorchvisionResNet as tv
+    from utils.helpers import get_class_model
+    assert sum(p.numel() for p in tv.resnet18().parameters()) == 11_689_512
+    assert sum(p.numel() for p in tv.resnet50().parameters()) == 25_557_032
+    m, head = get_class_model("resnet50", hub=True)
+    assert head == "fc" and isinstance(m.fc[0], torch.nn.Dropout) and m.fc[1].out_features == 3
+    assert "layer1.0.downsample.0.weight" in m.state_dict() and "layer1.1.downsample.0.weight" not in m.state_dict()
+    m.train()
+    m.engine.flatten()
+    plan = m.engine.plan_for((2, 3, 64, 64), True, True, torch.float32)
+    pools = [l for l in plan.fwd if l.name == "mi355_global_pool_fwd"]
+    assert len(pools) == 1 and pools[0].args[-2] == 0                      # is_max == 0: average
+    assert sum(l.name == "mi355_bn_finalize" for l in plan.fwd) == 53      # 49 block BNs + 4 downsample, bn1 once
+    local, _ = get_class_model("resnet50")
+    assert "layer1.0.identity.0.weight" in local.state_dict()              # default: the reference's offline fallback classes

@@ -496,6 +496,8 @@ class Builder:
         bn = 128 if co % 128 == 0 else (64 if co % 64 == 0 else 32)
         if self.dtype == torch.float32:
             return f"conv_igemm_kernel<f32,{bn},16>"
+        if os.environ.get("MI355_IGEMM_VARIANT") == "0":            # A/B switch of the launcher: register-staged generic kernel
+            return f"conv_igemm_kernel<bf16,{bn},{64 if ci % 64 == 0 else 32}>"
         if k == 3 and s == 1 and co % 64 == 0 and not (dgrad and up):
             if Wo % 32 == 0 and Ho % 8 == 0:
                 return "conv3x3_halo_rw_kernel<8,32>"
@@ -512,7 +514,8 @@ class Builder:
 
     def wgrad_tag(self, co, ci, k=1, s=1, Ho=0, Wo=0):
         t = "f32" if self.dtype == torch.float32 else "bf16"       # (the fp16 build runs the same variants as bf16)
-        if t == "bf16" and k == 3 and s == 1 and Ho % 8 == 0 and (Wo % 32 == 0 or Wo == 16):      # (Wo == 16: even batches)
+        halo = os.environ.get("MI355_WGRAD_HALO", "1") != "0"                                      # A/B switch of the launcher
+        if halo and t == "bf16" and k == 3 and s == 1 and Ho % 8 == 0 and (Wo % 32 == 0 or Wo == 16):      # (Wo == 16: even batches)
             return "wgrad3x3_halo_kernel"
         return f"conv_wgrad_kernel<{t},{128 if co % 128 == 0 else 64},{128 if ci % 128 == 0 else 64}>"
 

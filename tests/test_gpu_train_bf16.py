@@ -1,9 +1,10 @@
-"""-m gpu: the north-star Dice criterion.  Train Attention U-Net for 40 optimiser steps on a learnable
+"""-m gpu: the north-star Dice criterion (configs C3 and C4 in their own dtypes).  Train Attention U-Net for 40 optimiser steps on a learnable
 synthetic task (ellipse visible in the image) three ways from identical weights and batches —
 HIP bf16, HIP fp16 (+ loss scaling, helpers.py:285,323-336), HIP fp32, CPU fp32 oracle (reference semantics:
 BCEWithLogits, clip 1.0, AdamW wd 5e-4) —
 and compare the Dice of the binarised predictions (tester.py:114-134) on 32 held-out images.
-Bound: |Dice - Dice_oracle| <= 1e-3 (0..1 scale) for every GPU mode; final losses within 2 %."""
+Bound: |Dice - Dice_oracle| <= 1e-3 (0..1 scale) for every GPU mode; final losses within 2 %.
+The same protocol runs R2AttU_Net (R2AttU_Net.py:88-158, config C4: bf16) for 20 steps against its fp32 oracle."""
 import pytest
 import torch
 
@@ -25,25 +26,30 @@ def _dice(logit, m):
     return float((2 * (p * t).sum() + 1e-7) / (p.sum() + t.sum() + 1e-7))
 
 
-def test_dice_after_training_matches_oracle():
+@pytest.mark.parametrize("name,steps,dtypes", [
+    ("AttentionUNet", 40, (torch.float32, torch.bfloat16, torch.float16)),          # C3 (bf16) and C5's segmenter (fp16)
+    ("R2AttU_Net", 20, (torch.float32, torch.bfloat16)),                            # C4 (bf16)
+])
+def test_dice_after_training_matches_oracle(name, steps, dtypes):
     from mi355 import nn as mnn, optim as moptim, amp as mamp
-    from models.segmentation_models.AttentionUNet import AttentionUNet
-    hw, b, steps, lr = 64, 4, 40, 1e-3
+    from utils.helpers import get_seg_model
+    hw, b, lr = 64, 4, 1e-3
     batches = [_task(b, hw, s) for s in range(4)]
     xv, mv = _task(32, hw, 99)
-    sd0 = nets.default_init_state("AttentionUNet", seed=0)
+    sd0 = nets.default_init_state(name, seed=0)
+    fwd = nets.NETS[name]
 
     sd = {k: v.clone() for k, v in sd0.items()}
     opt = otrain.AdamW(nets.param_keys(sd), lr)
     for i in range(steps):
         x, y = batches[i % 4]
-        ref_loss, _, _ = otrain.train_step("AttentionUNet", sd, x, y, opt, True)
+        ref_loss, _, _ = otrain.train_step(name, sd, x, y, opt, True)
     with torch.no_grad():
-        ref_dice = _dice(nets.attention_unet({k: v.clone() for k, v in sd.items()}, xv, True), mv)
+        ref_dice = _dice(fwd({k: v.clone() for k, v in sd.items()}, xv, True), mv)
     assert ref_dice > 0.95          # the task is learnable: the comparison is not degenerate
 
-    for dtype in (torch.float32, torch.bfloat16, torch.float16):
-        m = AttentionUNet()
+    for dtype in dtypes:
+        m = get_seg_model({"AttentionUNet": "attentionunet", "R2AttU_Net": "r2attunet"}[name])
         m.load_state_dict(sd0)
         m.compute_dtype = dtype
         m = m.to(DEV).train()
@@ -71,5 +77,5 @@ def test_dice_after_training_matches_oracle():
             assert it == steps
         with torch.no_grad():
             d = _dice(m(xv.to(DEV)).float().cpu(), mv)       # train-mode BN, like the oracle evaluation above
-        assert abs(d - ref_dice) <= 1e-3, (str(dtype), d, ref_dice)
-        assert abs(float(loss.detach()) - ref_loss) <= 0.02 * ref_loss, (str(dtype), float(loss.detach()), ref_loss)
+        assert abs(d - ref_dice) <= 1e-3, (name, str(dtype), d, ref_dice)
+        assert abs(float(loss.detach()) - ref_loss) <= 0.02 * ref_loss, (name, str(dtype), float(loss.detach()), ref_loss)

@@ -302,6 +302,22 @@ int mi355_mask_scatter(const float* logit, const int32_t* idx, int n, long long 
 int mi355_seg_counts(const float* prob_or_logit, const float* target, float* counts, int B, long long per,
                      int is_logit, float thr, mi355_stream_t s);
 
+/* ---- launch-plan replay: the per-batch host loop of utils/helpers.py:317-342 (model(x) ... loss.backward()) as ONE call ---- */
+/* A plan is a table of pre-resolved launches of the entry points above: `name`, its arguments as 64-bit slots in prototype
+ * order INCLUDING the trailing stream (pointers and integers by value, floats as their IEEE-754 bit pattern in the low 32
+ * bits), flags bit 0 = "runs on the side stream" (weight-gradient launches).  mi355_plan_run issues launches [first, last) in
+ * order; whenever a run of side-stream launches starts, the side stream first waits for everything issued on the main stream
+ * so far (event fork).  mi355_plan_join makes the main stream wait for the side stream.  Nothing synchronises with the host.
+ * mi355_plan_arity(name) = number of slots the entry point takes, or -1 if `name` is not a launcher of this header. */
+int mi355_plan_arity(const char* name);
+void* mi355_plan_create(int n);
+int mi355_plan_set(void* plan, int i, const char* name, const uint64_t* args, int nargs, int flags);
+int mi355_plan_patch(void* plan, int i, int arg, uint64_t value);
+int mi355_plan_run(void* plan, int first, int last, mi355_stream_t main_stream, mi355_stream_t side_stream);
+int mi355_plan_join(void* plan, mi355_stream_t main_stream, mi355_stream_t side_stream);
+int mi355_plan_last_index(void* plan);
+int mi355_plan_destroy(void* plan);
+
 #ifdef __cplusplus
 }
 #endif

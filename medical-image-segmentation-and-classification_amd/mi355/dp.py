@@ -88,17 +88,18 @@ class DataParallel:
         dist.all_reduce(self.engine.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
 
     def _run_backward(self, plan, stream):
-        calls = plan.bind(stream)[1]
+        plan.bind(stream)
+        n = len(plan.bwd)
         buckets = self.schedule(plan)
-        run = self.run_calls or plan.run_calls_two_streams
+        run = self.run_calls or (lambda first, last: plan.run_backward_range(stream, first, last))
         if not self.overlap or not self.engine.flat_g.is_cuda:
             start = 0
             for ready, lo, hi in buckets:         # same order as the overlapped path, executed serially
-                run(calls[start:ready + 1])
+                run(start, ready + 1)
                 start = ready + 1
                 plan.join_side()
                 self._allreduce(lo, hi)
-            run(calls[start:])
+            run(start, n)
             plan.join_side()
             return
         if self.comm_stream is None:
@@ -106,7 +107,7 @@ class DataParallel:
         main = torch.cuda.current_stream()
         start = 0
         for ready, lo, hi in buckets:
-            run(calls[start:ready + 1])
+            run(start, ready + 1)
             start = ready + 1
             ev = torch.cuda.Event()
             ev.record(main)
@@ -119,7 +120,7 @@ class DataParallel:
                 if ev_side is not None:
                     self.comm_stream.wait_event(ev_side)
                 self._allreduce(lo, hi)
-        run(calls[start:])
+        run(start, n)
         plan.join_side()
         main.wait_stream(self.comm_stream)
 

@@ -124,14 +124,9 @@ class Engine:
     def run_forward(self, plan, x):
         if x.dtype != torch.float32 or not x.is_contiguous():
             x = x.float().contiguous()
-        pre_fwd, _ = plan.bind(self._stream())
-        fn, args, name, _ = pre_fwd[0]                   # mi355_pack_input_nchw reads the caller's tensor in place
-        rc = fn(x.data_ptr(), *args[1:])
-        if rc:
-            raise RuntimeError(f"{name} failed (rc={rc}): {lib.raw('mi355_last_error')().decode()}")
         if plan.training and getattr(plan, "has_dropout", False):
             self._drop_counter += 1
-        graph.Plan._run(pre_fwd[1:])
+        plan.run_forward(self._stream(), x.data_ptr())      # mi355_pack_input_nchw reads the caller's tensor in place
         kind, buf, shape = plan.output
         t = buf if kind == "z" else buf.buf
         return t[: int(torch.Size(shape).numel())].view(shape)

@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import struct
 from typing import List, Optional
 
 import torch
@@ -123,6 +124,9 @@ class Plan:
         self.param_ptrs = [(p, p.data_ptr()) for p in b.params_seen]
         self.grad_params = list(b.grad_params)   # parameters that receive a gradient, in write order
         self._bound = {}
+        self._cplans = {}                 # stream -> (forward plan, backward plan, side stream) handles of csrc/plan.cpp
+        self._chandles = []
+        self.replay_in_c = os.environ.get("MI355_PLAN_C", "1") != "0"
         self._side = None
         self.side_stream_enabled = os.environ.get("MI355_SIDE_STREAM", "1") != "0"
         self.n_launches = (len(self.pre) + len(self.fwd), len(self.bwd))
@@ -178,7 +182,44 @@ class Plan:
             for l in self.bwd:
                 bwd.extend(self._resolve([l], side if (l.side and side is not None) else stream))
             self._bound[key] = (fwd, bwd)
+            if self.replay_in_c:
+                self._cplans[key] = (self._to_c(fwd, False), self._to_c(bwd, side is not None), side)
         return self._bound[key]
+
+    # -- replay in C: the resolved tables are handed to csrc/plan.cpp once; a step is then 2-3 calls (mi355_plan_run) ----------
+    def _to_c(self, resolved, with_side):
+        create, pset = lib.raw("mi355_plan_create"), lib.raw("mi355_plan_set")
+        cp = create(len(resolved))
+        if not cp:
+            raise RuntimeError("mi355_plan_create failed")
+        self._chandles.append(cp)
+        for i, (fn, args, name, l) in enumerate(resolved):
+            types = [t for t, _ in lib.protos[name][1]]
+            slots = (ctypes.c_uint64 * len(args))()
+            for j, (v, t) in enumerate(zip(args, types)):
+                if v is None:
+                    slots[j] = 0
+                elif t is ctypes.c_float:
+                    slots[j] = struct.unpack("<I", struct.pack("<f", float(v)))[0]
+                else:
+                    slots[j] = int(v) & 0xFFFFFFFFFFFFFFFF
+            rc = pset(cp, i, name.encode(), slots, len(args), 1 if (with_side and l.side) else 0)
+            if rc:
+                raise RuntimeError(f"mi355_plan_set({name}) failed (rc={rc}): {lib.raw('mi355_last_error')().decode()}")
+        return cp
+
+    def _c_fail(self, cp, rc, calls):
+        i = lib.raw("mi355_plan_last_index")(cp)
+        name = calls[i][2] if 0 <= i < len(calls) else "?"
+        raise RuntimeError(f"{name} (launch {i}) failed (rc={rc}): {lib.raw('mi355_last_error')().decode()}")
+
+    def __del__(self):
+        try:
+            destroy = lib.raw("mi355_plan_destroy")
+            for cp in self._chandles:
+                destroy(cp)
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
 
     @staticmethod
     def _run(calls):
@@ -187,11 +228,28 @@ class Plan:
             if rc:
                 raise RuntimeError(f"{name} failed (rc={rc}): {lib.raw('mi355_last_error')().decode()}")
 
-    def run_forward(self, stream):
-        self._run(self.bind(stream)[0])
+    def run_forward(self, stream, x_ptr=None):
+        """pre + forward launches; ``x_ptr``: the caller's NCHW fp32 input (read in place by the first launch)."""
+        calls = self.bind(stream)[0]
+        key = int(stream or 0)
+        if self.replay_in_c:
+            cp = self._cplans[key][0]
+            if x_ptr is not None:
+                lib.raw("mi355_plan_patch")(cp, 0, 0, x_ptr)
+            rc = lib.raw("mi355_plan_run")(cp, 0, len(calls), stream, None)
+            if rc:
+                self._c_fail(cp, rc, calls)
+            return
+        if x_ptr is not None:
+            fn, args, name, _ = calls[0]
+            rc = fn(x_ptr, *args[1:])
+            if rc:
+                raise RuntimeError(f"{name} failed (rc={rc}): {lib.raw('mi355_last_error')().decode()}")
+            calls = calls[1:]
+        self._run(calls)
 
     def run_calls_two_streams(self, calls):
-        """Run a slice of the bound backward list, forking side-flagged groups onto the side stream."""
+        """Run a slice of the bound backward list, forking side-flagged groups onto the side stream (Python loop)."""
         if self._side is None:
             self._run(calls)
             return
@@ -207,12 +265,23 @@ class Plan:
             if rc:
                 raise RuntimeError(f"{name} failed (rc={rc}): {lib.raw('mi355_last_error')().decode()}")
 
+    def run_backward_range(self, stream, first, last):
+        """Backward launches [first, last) (the data-parallel runner interleaves all-reduces between ranges)."""
+        calls = self.bind(stream)[1]
+        if self.replay_in_c:
+            _, cp, side = self._cplans[int(stream or 0)]
+            rc = lib.raw("mi355_plan_run")(cp, first, last, stream, side)
+            if rc:
+                self._c_fail(cp, rc, calls)
+        else:
+            self.run_calls_two_streams(calls[first:last])
+
     def join_side(self):
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
 
     def run_backward(self, stream):
-        self.run_calls_two_streams(self.bind(stream)[1])
+        self.run_backward_range(stream, 0, len(self.bwd))
         self.join_side()
 
     def params_moved(self):

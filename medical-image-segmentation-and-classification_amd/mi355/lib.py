@@ -33,7 +33,7 @@ def parse_header(path=HEADER):
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     protos = {}
-    for m in re.finditer(r"\b(int|const char\*)\s+(mi355_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(int|const char\*|void\*)\s+(mi355_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         arglist = []
         if args and args != "void":
@@ -45,7 +45,7 @@ def parse_header(path=HEADER):
                     ty, nm = a.rsplit(" ", 1)
                     ty = ty.replace("const ", "").strip()
                     arglist.append((_CTYPES[ty], nm))
-        protos[name] = (ctypes.c_char_p if ret != "int" else ctypes.c_int, arglist)
+        protos[name] = ({"int": ctypes.c_int, "const char*": ctypes.c_char_p, "void*": ctypes.c_void_p}[ret], arglist)
     return protos
 
 

@@ -41,3 +41,28 @@ def test_argument_errors_are_reported_without_a_gpu():
     fn.argtypes = [t for t, _ in L.parse_header()["mi355_conv2d_igemm"][1]]
     rc = fn(None, None, None, None, 1, 4, 4, 32, 32, 4, 4, 32, 32, 3, 3, 1, 1, -1, 1, 0, 0, None, 0, None)
     assert rc == -1 and b"null" in dll.mi355_last_error()
+
+
+@pytest.mark.skipif(not os.path.exists(L.SO_PATH), reason="libmi355conv.so not built")
+def test_plan_replay_knows_every_launcher_with_its_arity():
+    """csrc/plan.cpp reaches a launcher through a trampoline typed by its prototype: every `int mi355_*` entry point of the
+    header has one (with the header's arity), a table is rejected on a wrong name / arity, and launch arguments are
+    validated by the launcher itself when the plan runs (here: without a GPU, a null-pointer launch fails cleanly)."""
+    lib = L.lib
+    arity = lib.raw("mi355_plan_arity")
+    for name, (ret, args) in L.parse_header().items():
+        if ret is ctypes.c_int and not name.startswith("mi355_plan_"):
+            assert arity(name.encode()) == len(args), name
+    assert arity(b"mi355_no_such_launcher") == -1
+    create, pset, run = lib.raw("mi355_plan_create"), lib.raw("mi355_plan_set"), lib.raw("mi355_plan_run")
+    cp = create(2)
+    assert cp
+    n = len(L.parse_header()["mi355_conv2d_igemm"][1])
+    slots = (ctypes.c_uint64 * n)()
+    assert pset(cp, 0, b"mi355_conv2d_igemm", slots, n - 1, 0) == -1 and b"takes 24" in lib.raw("mi355_last_error")()
+    assert pset(cp, 0, b"mi355_bogus", slots, n, 0) == -1
+    assert pset(cp, 5, b"mi355_conv2d_igemm", slots, n, 0) == -1
+    assert pset(cp, 0, b"mi355_conv2d_igemm", slots, n, 0) == 0
+    assert run(cp, 0, 2, None, None) == -1 and lib.raw("mi355_plan_last_index")(cp) == 0       # null pointers: rejected by the launcher
+    assert b"null" in lib.raw("mi355_last_error")()
+    assert lib.raw("mi355_plan_destroy")(cp) == 0

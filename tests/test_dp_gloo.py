@@ -63,8 +63,8 @@ def _worker(rank, world, port, bucket_mb, q):
         log = []
         real_allreduce = dp._allreduce
 
-        def fake_run(calls):
-            for fn, args, name, l in calls:
+        def fake_run(first, last):
+            for fn, args, name, l in plan.bind(0)[1][first:last]:
                 for a in l.args:
                     if isinstance(a, graph.GRef):
                         o, n = eng.offsets[id(a.param)]

@@ -505,6 +505,7 @@ static int launch_dma(const ConvArgs& a, hipStream_t s) {
 }
 
 #include "conv3x3_halo.hpp"
+#include "conv3x3_halo_pp.hpp"
 #include "conv1x1_stream.hpp"
 
 template <typename T, int BN, int BK>
@@ -522,7 +523,7 @@ static int launch_bn(const ConvArgs& a, hipStream_t s) {
   return launch<T, 32, BK>(a, s);
 }
 
-enum IgemmVariant { IG_GENERIC = 0, IG_DMA, IG_HALO_8x32, IG_HALO_16x16, IG_STREAM1x1 };
+enum IgemmVariant { IG_GENERIC = 0, IG_DMA, IG_HALO_8x32, IG_HALO_16x16, IG_STREAM1x1, IG_HALO_PP };
 
 // ONE place that decides which kernel serves a shape (also used by the statistics-row query).
 static IgemmVariant pick_variant(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int mul, int kmul, int off,
@@ -535,6 +536,9 @@ static IgemmVariant pick_variant(int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
   const bool is3x3s1 = KH == 3 && KW == 3 && mul == 1 && div == 1 && Ho == Hlog && Wo == Wlog &&
                        ((kmul == 1 && off == -1) || (kmul == -1 && off == 1 && !up));
   if (is3x3s1 && Co % 64 == 0) {
+    // 16 x 32 tiles, two phase-shifted halves per workgroup (conv3x3_halo_pp.hpp); MI355_HALO_PP=0: the 4-wave kernel (A/B)
+    static const int use_pp = getenv("MI355_HALO_PP") ? atoi(getenv("MI355_HALO_PP")) : 1;
+    if (use_pp && Wo % 32 == 0 && Ho % 16 == 0) return IG_HALO_PP;
     if (Wo % 32 == 0 && Ho % 8 == 0) return IG_HALO_8x32;
     if (Wo % 16 == 0 && Ho % 16 == 0) return IG_HALO_16x16;
   }
@@ -553,6 +557,7 @@ extern "C" int mi355_conv2d_igemm_variant(int Hi, int Wi, int Ci, int Ho, int Wo
 extern "C" int mi355_conv2d_igemm_stat_rows(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int mul,
                                             int kmul, int off, int div, int up, int dtype) {
   switch (pick_variant(Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up, dtype)) {
+    case IG_HALO_PP: return N * (Ho / 16) * (Wo / 32);
     case IG_HALO_8x32: return N * (Ho / 8) * (Wo / 32);
     case IG_HALO_16x16: return N * (Ho / 16) * (Wo / 16);
     case IG_DMA: return ceil_div((long long)N * Ho * Wo, 128);
@@ -590,7 +595,7 @@ extern "C" int mi355_conv2d_igemm(const void* in, const void* wk, const float* b
   a.accumulate = accumulate & 1;
   a.relu = (accumulate >> 1) & 1;
   a.pool2 = (accumulate >> 2) & 1;
-  MI355_CHECK_ARG(!a.pool2 || ((v == IG_HALO_8x32 || v == IG_HALO_16x16) && !stats),
+  MI355_CHECK_ARG(!a.pool2 || ((v == IG_HALO_8x32 || v == IG_HALO_16x16 || v == IG_HALO_PP) && !stats),
                   "conv2d_igemm: the 2x2-sum epilogue exists for the halo kernel only (mi355_conv2d_igemm_variant >= 2)");
   a.stats = stats;
   a.M = N * Ho * Wo;
@@ -604,6 +609,7 @@ extern "C" int mi355_conv2d_igemm(const void* in, const void* wk, const float* b
     using T = decltype(tag);
     if constexpr (sizeof(T) == 2) {
       switch (v) {
+        case IG_HALO_PP: return launch_halo_pp<T>(a, st);
         case IG_HALO_8x32: return launch_halo_rw<T, 8, 32>(a, st);
         case IG_HALO_16x16: return launch_halo_rw<T, 16, 16>(a, st);
         case IG_STREAM1x1: return launch_stream1x1<T>(a, st);

@@ -115,6 +115,7 @@ class Plan:
         self.training = b.training
         self.pre, self.fwd, self.bwd = b.pre, b.fwd, b.bwd
         self.keep = b.keep
+        self.acts = b.acts                # [(kind, handles...)] in forward order: activations at the network's kinks (tests / diagnostics)
         self.input = b.input
         self.output = b.output            # ("z", tensor[M], N,H,W) or ("v", V)
         self.dout = b.dout                # fp32 buffer the loss writes dL/dlogits into
@@ -319,6 +320,7 @@ class Builder:
         self.output = None
         self.dout = None
         self.bn_momentum = 0.1
+        self.acts = []                   # ("relu", a) | ("relu_pre", y, scale, shift[, res]) | ("pool", x, y, k, s, p): see Plan.acts
 
     # ---- allocation ---------------------------------------------------------------------------
     def _alloc(self, numel, dtype=None):
@@ -527,7 +529,7 @@ class Builder:
                     acc = self.acc_flag(x)
                     xg = self.grad_of(x)
                     tag = self.igemm_tag(x.C, Co, k, s, 2 * x.H, 2 * x.W, True, False, M=x.N * 4 * x.H * x.W)
-                    if lib.mi355_conv2d_igemm_variant(Ho, Wo, Co, 2 * x.H, 2 * x.W, x.C, k, k, 1, -1, p, s, 0, self.code) in (2, 3):
+                    if lib.mi355_conv2d_igemm_variant(Ho, Wo, Co, 2 * x.H, 2 * x.W, x.C, k, k, 1, -1, p, s, 0, self.code) in (2, 3, 5):
                         # the data gradient lives on the up-sampled grid; its 2x2 sums go straight to the half-resolution
                         # gradient in the kernel epilogue (no full-resolution temporary, no separate pass)
                         self.bwd.append(Launch("mi355_conv2d_igemm", dy, wb, None, xg, x.N, Ho, Wo, Co, dy.ld, 2 * x.H, 2 * x.W,
@@ -568,6 +570,8 @@ class Builder:
         if os.environ.get("MI355_IGEMM_VARIANT") == "0":            # A/B switch of the launcher: register-staged generic kernel
             return f"conv_igemm_kernel<bf16,{bn},{64 if ci % 64 == 0 else 32}>"
         if k == 3 and s == 1 and co % 64 == 0 and not (dgrad and up):
+            if Wo % 32 == 0 and Ho % 16 == 0 and os.environ.get("MI355_HALO_PP", "1") != "0":
+                return "conv3x3_halo_pp_kernel"
             if Wo % 32 == 0 and Ho % 8 == 0:
                 return "conv3x3_halo_rw_kernel<8,32>"
             if Wo % 16 == 0 and Ho % 16 == 0:
@@ -706,6 +710,8 @@ class Builder:
                                r, r.ld if r is not None else 0, a, a.ld, y.M, y.C, flags, self.code,
                                nbytes=(2 + (r is not None)) * y.M * y.C * self.esz))
         a.needs_grad = y.needs_grad or bn.weight.requires_grad or (r is not None and r.needs_grad)
+        if act:
+            self.acts.append(("relu", a) if post_add is None else ("relu_pre", y, st["scale"], st["shift"]))
 
         def rule():
             if not a.needs_grad:
@@ -745,6 +751,7 @@ class Builder:
             self.rule(rule)
             return y
         a = y                                                                 # (relu'(.) is recovered from a > 0)
+        self.acts.append(("relu", a))
 
         def rule():
             if not a.needs_grad:
@@ -796,6 +803,7 @@ class Builder:
         Ho, Wo = (x.H + 2 * p - k) // s + 1, (x.W + 2 * p - k) // s + 1
         y = self.new_tensor(x.N, Ho, Wo, x.C)
         self.fwd.append(Launch("mi355_maxpool_fwd", x, x.ld, y, y.ld, x.N, x.H, x.W, x.C, k, s, p, self.code))
+        self.acts.append(("pool", x, y, k, s, p))
         y.needs_grad = x.needs_grad
 
         def rule():
@@ -862,6 +870,7 @@ class Builder:
         p = self.new_tensor(x.N, x.H, x.W, F_int)
         self.fwd.append(Launch("mi355_bn_act", g1, g1.ld, sg["scale"], sg["shift"], x1, x1.ld, sx["scale"], sx["shift"],
                                None, 0, p, p.ld, M, F_int, 1, self.code))
+        self.acts.append(("relu", p))
         z = self.f32(M)
         nb = lib.mi355_rowreduce_blocks(M)
         sp = {k: self.f32(1) for k in ("scale", "shift", "mean", "invstd")}

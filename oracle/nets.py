@@ -44,6 +44,58 @@ def _bn(sd, p, x, training):
         training, BN_MOMENTUM, BN_EPS)
 
 
+# ----------------------------------------------------------------------------
+# kinks: the network's non-smooth decisions (ReLU masks, max-pool arg-max)
+# ----------------------------------------------------------------------------
+class Kinks:
+    """Record / replay of every ReLU mask and max-pool arg-max of one forward, in call order.
+
+    The gradient of these networks is discontinuous in the weights and inputs: an fp32 evaluation that lands a
+    pre-activation on the other side of zero than fp64 (a dozen of ~10^7 elements do) changes that element's gradient by
+    100 % and every parameter gradient by ~1e-3 relative — for ANY fp32 implementation, the reference's CPU path included.
+    Replaying the masks of one evaluation (``replay``: ``relu(x) := x * mask``, ``maxpool := gather at the recorded
+    arg-max``) inside another makes the two evaluate the SAME smooth function, so that their gradients can be compared to
+    rounding accuracy (tests/test_gpu_kinks.py).  Off (``mode is None``) the wrappers are plain F.relu / F.max_pool2d."""
+    mode = None
+    relu, pool = [], []
+    i_relu = i_pool = 0
+
+    @classmethod
+    def start(cls, mode, relu=None, pool=None):
+        cls.mode, cls.relu, cls.pool = mode, (relu if relu is not None else []), (pool if pool is not None else [])
+        cls.i_relu = cls.i_pool = 0
+
+    @classmethod
+    def stop(cls):
+        r, p = cls.relu, cls.pool
+        used = (cls.i_relu, cls.i_pool)
+        cls.mode, cls.relu, cls.pool = None, [], []
+        return r, p, used
+
+
+def _relu(x):
+    if Kinks.mode == "record":
+        Kinks.relu.append((x > 0).detach())
+    elif Kinks.mode == "replay":
+        m = Kinks.relu[Kinks.i_relu]
+        Kinks.i_relu += 1
+        assert m.shape == x.shape, (m.shape, x.shape)
+        return x * m.to(x.dtype)
+    return F.relu(x)
+
+
+def _maxpool(x, k, s, p=0):
+    if Kinks.mode == "record":
+        y, idx = F.max_pool2d(x, k, s, p, return_indices=True)
+        Kinks.pool.append(idx.detach())
+        return y
+    if Kinks.mode == "replay":
+        idx = Kinks.pool[Kinks.i_pool]
+        Kinks.i_pool += 1
+        return x.flatten(2).gather(2, idx.flatten(2)).view(idx.shape)
+    return F.max_pool2d(x, k, s, p)
+
+
 def _up2(x):
     return F.interpolate(x, scale_factor=2.0, mode="nearest")
 
@@ -57,20 +109,20 @@ def _linear(sd, p, x):
 # ----------------------------------------------------------------------------
 def double_conv(sd, p, x, tr):
     """basic_block (AttentionUNet.py:4-13): indices 0 conv,1 bn,3 conv,4 bn."""
-    x = F.relu(_bn(sd, p + ".1", _conv(sd, p + ".0", x, 1, 1), tr))
-    return F.relu(_bn(sd, p + ".4", _conv(sd, p + ".3", x, 1, 1), tr))
+    x = _relu(_bn(sd, p + ".1", _conv(sd, p + ".0", x, 1, 1), tr))
+    return _relu(_bn(sd, p + ".4", _conv(sd, p + ".3", x, 1, 1), tr))
 
 
 def up_conv(sd, p, x, tr):
     """UpConv (AttentionUNet.py:15-27): nearest x2, conv3x3, bn, relu."""
-    return F.relu(_bn(sd, p + ".up.2", _conv(sd, p + ".up.1", _up2(x), 1, 1), tr))
+    return _relu(_bn(sd, p + ".up.2", _conv(sd, p + ".up.1", _up2(x), 1, 1), tr))
 
 
 def attention_gate(sd, p, g, x, tr):
     """AttentionGate (AttentionUNet.py:29-54)."""
     g1 = _bn(sd, p + ".W_g.1", _conv(sd, p + ".W_g.0", g), tr)
     x1 = _bn(sd, p + ".W_x.1", _conv(sd, p + ".W_x.0", x), tr)
-    a = F.relu(g1 + x1)
+    a = _relu(g1 + x1)
     psi = torch.sigmoid(_bn(sd, p + ".psi.1", _conv(sd, p + ".psi.0", a), tr))
     return x * psi
 
@@ -78,7 +130,7 @@ def attention_gate(sd, p, g, x, tr):
 def recurrent(sd, p, x, t, tr):
     """Recurrent_block (R2AttU_Net.py:29-45): f(x) then t times f(x + x1)."""
     def f(z):
-        return F.relu(_bn(sd, p + ".conv.1", _conv(sd, p + ".conv.0", z, 1, 1), tr))
+        return _relu(_bn(sd, p + ".conv.1", _conv(sd, p + ".conv.0", z, 1, 1), tr))
     x1 = f(x)
     for _ in range(t):
         x1 = f(x + x1)
@@ -97,7 +149,7 @@ def rrcnn(sd, p, x, t, tr):
 # ----------------------------------------------------------------------------
 def attention_unet(sd, x, training=False):
     tr = training
-    mp = lambda z: F.max_pool2d(z, 2, 2)
+    mp = lambda z: _maxpool(z, 2, 2)
     x1 = double_conv(sd, "conv1", x, tr)
     x2 = double_conv(sd, "conv2", mp(x1), tr)
     x3 = double_conv(sd, "conv3", mp(x2), tr)
@@ -113,7 +165,7 @@ def attention_unet(sd, x, training=False):
 
 def _r2_family(sd, x, training, t, gated):
     tr = training
-    mp = lambda z: F.max_pool2d(z, 2, 2)
+    mp = lambda z: _maxpool(z, 2, 2)
     x1 = rrcnn(sd, "RRCNN1", x, t, tr)
     x2 = rrcnn(sd, "RRCNN2", mp(x1), t, tr)
     x3 = rrcnn(sd, "RRCNN3", mp(x2), t, tr)
@@ -145,9 +197,9 @@ def _basic_block(sd, p, x, stride, tr):
     idn = x
     if (p + ".identity.0.weight") in sd:
         idn = _bn(sd, p + ".identity.1", _conv(sd, p + ".identity.0", x, stride, 0), tr)
-    y = F.relu(_bn(sd, p + ".bn1", _conv(sd, p + ".conv1", x, stride, 1), tr))
+    y = _relu(_bn(sd, p + ".bn1", _conv(sd, p + ".conv1", x, stride, 1), tr))
     y = _bn(sd, p + ".bn2", _conv(sd, p + ".conv2", y, 1, 1), tr)
-    return F.relu(y + idn)
+    return _relu(y + idn)
 
 
 def _bottleneck_local(sd, p, x, stride, tr):
@@ -155,10 +207,10 @@ def _bottleneck_local(sd, p, x, stride, tr):
     idn = x
     if (p + ".identity.0.weight") in sd:
         idn = _bn(sd, p + ".identity.1", _conv(sd, p + ".identity.0", x, stride, 0), tr)
-    y = F.relu(_bn(sd, p + ".bn1", _conv(sd, p + ".conv1", x, stride, 0), tr))
-    y = F.relu(_bn(sd, p + ".bn2", _conv(sd, p + ".conv2", y, 1, 1), tr))
+    y = _relu(_bn(sd, p + ".bn1", _conv(sd, p + ".conv1", x, stride, 0), tr))
+    y = _relu(_bn(sd, p + ".bn2", _conv(sd, p + ".conv2", y, 1, 1), tr))
     y = _bn(sd, p + ".bn3", _conv(sd, p + ".conv3", y, 1, 0), tr)
-    return F.relu(y + idn)
+    return _relu(y + idn)
 
 
 def _head(sd, p, x, training, drop_mask=None):
@@ -178,8 +230,8 @@ def _resnet_local(sd, x, training, block, counts, drop_mask):
     (lines 130,134 / 185,189) and the global pool is AdaptiveMaxPool2d (112/167)."""
     tr = training
     x = _conv(sd, "conv1", x, 2, 3)
-    x = F.relu(_bn(sd, "bn1", x, tr))
-    x = F.max_pool2d(x, 3, 2, 1)
+    x = _relu(_bn(sd, "bn1", x, tr))
+    x = _maxpool(x, 3, 2, 1)
     x = _bn(sd, "bn1", x, tr)
     for li, n in enumerate(counts, start=1):
         for b in range(n):
@@ -210,17 +262,17 @@ def _vgg(sd, x, cfg, training, drop_masks):
     idx = 0
     for c in cfg:
         if c == "M":
-            x = F.max_pool2d(x, 2, 2)
+            x = _maxpool(x, 2, 2)
             idx += 1
         else:
-            x = F.relu(_conv(sd, f"features.{idx}", x, 1, 1))
+            x = _relu(_conv(sd, f"features.{idx}", x, 1, 1))
             idx += 2
     x = F.adaptive_avg_pool2d(x, 1).flatten(1)
     dm = list(drop_masks) if (training and drop_masks is not None) else []
-    x = F.relu(_linear(sd, "classifier.2", x))
+    x = _relu(_linear(sd, "classifier.2", x))
     if dm:
         x = x * dm[0]
-    x = F.relu(_linear(sd, "classifier.5", x))
+    x = _relu(_linear(sd, "classifier.5", x))
     if dm:
         x = x * dm[1]
     if "classifier.9.weight" in sd:          # after add_dropout_to_fc
@@ -239,17 +291,17 @@ def _vgg_bn(sd, x, cfg, training, drop_masks):
     idx = 0
     for c in cfg:
         if c == "M":
-            x = F.max_pool2d(x, 2, 2)
+            x = _maxpool(x, 2, 2)
             idx += 1
         else:
-            x = F.relu(_bn(sd, f"features.{idx + 1}", _conv(sd, f"features.{idx}", x, 1, 1), training))
+            x = _relu(_bn(sd, f"features.{idx + 1}", _conv(sd, f"features.{idx}", x, 1, 1), training))
             idx += 3
     x = F.adaptive_avg_pool2d(x, (7, 7)).flatten(1)
     dm = list(drop_masks) if (training and drop_masks is not None) else []
-    x = F.relu(_linear(sd, "classifier.0", x))
+    x = _relu(_linear(sd, "classifier.0", x))
     if dm:
         x = x * dm[0]
-    x = F.relu(_linear(sd, "classifier.3", x))
+    x = _relu(_linear(sd, "classifier.3", x))
     if dm:
         x = x * dm[1]
     if "classifier.7.weight" in sd:          # after add_dropout_to_fc
@@ -283,10 +335,10 @@ def _bottleneck_tv(sd, p, x, stride, tr):
     idn = x
     if (p + ".downsample.0.weight") in sd:
         idn = _bn(sd, p + ".downsample.1", _conv(sd, p + ".downsample.0", x, stride, 0), tr)
-    y = F.relu(_bn(sd, p + ".bn1", _conv(sd, p + ".conv1", x, 1, 0), tr))
-    y = F.relu(_bn(sd, p + ".bn2", _conv(sd, p + ".conv2", y, stride, 1), tr))
+    y = _relu(_bn(sd, p + ".bn1", _conv(sd, p + ".conv1", x, 1, 0), tr))
+    y = _relu(_bn(sd, p + ".bn2", _conv(sd, p + ".conv2", y, stride, 1), tr))
     y = _bn(sd, p + ".bn3", _conv(sd, p + ".conv3", y, 1, 0), tr)
-    return F.relu(y + idn)
+    return _relu(y + idn)
 
 
 def _decoder_block(sd, p, down, skip, tr):
@@ -297,8 +349,8 @@ def _decoder_block(sd, p, down, skip, tr):
 
 def resnet_unet(sd, x, training=False):
     tr = training
-    e1 = F.relu(_bn(sd, "encoder1.1", _conv(sd, "encoder1.0", x, 2, 3), tr))
-    y = F.max_pool2d(e1, 3, 2, 1)
+    e1 = _relu(_bn(sd, "encoder1.1", _conv(sd, "encoder1.0", x, 2, 3), tr))
+    y = _maxpool(e1, 3, 2, 1)
     feats = []
     for name, n, first_stride in (("encoder2", 3, 1), ("encoder3", 4, 2), ("encoder4", 6, 2),
                                   ("encoder5", 3, 2)):
@@ -311,7 +363,7 @@ def resnet_unet(sd, x, training=False):
     d = _decoder_block(sd, "decoder3", d, e2, tr)
     d = _decoder_block(sd, "decoder2", d, e1, tr)
     d = F.conv_transpose2d(d, sd["decoder1.0.weight"], sd["decoder1.0.bias"], stride=2)
-    d = F.relu(_bn(sd, "decoder1.2", _conv(sd, "decoder1.1", d, 1, 1), tr))
+    d = _relu(_bn(sd, "decoder1.2", _conv(sd, "decoder1.1", d, 1, 1), tr))
     return _conv(sd, "out", d)
 
 
@@ -320,17 +372,17 @@ def _basic_block_tv(sd, p, x, stride, tr):
     idn = x
     if (p + ".downsample.0.weight") in sd:
         idn = _bn(sd, p + ".downsample.1", _conv(sd, p + ".downsample.0", x, stride, 0), tr)
-    y = F.relu(_bn(sd, p + ".bn1", _conv(sd, p + ".conv1", x, stride, 1), tr))
+    y = _relu(_bn(sd, p + ".bn1", _conv(sd, p + ".conv1", x, stride, 1), tr))
     y = _bn(sd, p + ".bn2", _conv(sd, p + ".conv2", y, 1, 1), tr)
-    return F.relu(y + idn)
+    return _relu(y + idn)
 
 
 def _resnet_tv(sd, x, training, block, counts, drop_mask):
     """torchvision ResNet (the hub models helpers.py:158-161 asks for): one bn1, global AVERAGE pool — parity
     unpinned (restated from torchvision's public architecture; torchvision is absent here)."""
     tr = training
-    x = F.relu(_bn(sd, "bn1", _conv(sd, "conv1", x, 2, 3), tr))
-    x = F.max_pool2d(x, 3, 2, 1)
+    x = _relu(_bn(sd, "bn1", _conv(sd, "conv1", x, 2, 3), tr))
+    x = _maxpool(x, 3, 2, 1)
     for li, n in enumerate(counts, start=1):
         for b in range(n):
             x = block(sd, f"layer{li}.{b}", x, 2 if (li > 1 and b == 0) else 1, tr)

@@ -27,6 +27,14 @@ CASES = [  # N, Ci, H, W, Co, K, stride, pad, up
     (2, 96, 16, 16, 192, 3, 1, 1, 0),
     (2, 64, 8, 16, 128, 3, 1, 1, 1),
     (1, 128, 24, 32, 64, 3, 1, 1, 0),
+    # ping-pong halo kernel (conv3x3_halo_pp.hpp: H % 16 == 0, W % 32 == 0): one / three / five 32-channel slabs (odd and even
+    # slab counts take different exits of the unrolled loop), several tiles per image in both directions, fused up-sampling
+    (1, 32, 16, 32, 64, 3, 1, 1, 0),
+    (2, 96, 32, 64, 64, 3, 1, 1, 0),
+    (1, 160, 48, 32, 128, 3, 1, 1, 0),
+    (3, 64, 16, 96, 192, 3, 1, 1, 0),
+    (2, 64, 16, 32, 64, 3, 1, 1, 1),
+    (1, 256, 16, 32, 64, 3, 1, 1, 0),
 ]
 
 
@@ -77,10 +85,12 @@ def test_conv_dgrad(case, dtype):
     assert rel_err(from_nhwc(dx), ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("hw", [(8, 8), (16, 32), (32, 32)])          # generic / ping-pong halo kernel (one and two tiles per image)
 @pytest.mark.parametrize("dtype", DT)
-def test_conv_strided_slices_and_accumulate(dtype):
-    """input read from / output written into channel slices of wider buffers; accumulate flag."""
-    n, ci, h, w_, co = 2, 32, 8, 8, 64
+def test_conv_strided_slices_and_accumulate(dtype, hw):
+    """input read from / output written into channel slices of wider buffers; accumulate flag; ReLU epilogue."""
+    n, ci, co = 2, 32, 64
+    h, w_ = hw
     g = torch.Generator().manual_seed(3)
     x = torch.randn(n, ci, h, w_, generator=g); w = torch.randn(co, ci, 3, 3, generator=g) * 0.1
     ref = F.conv2d(q(x, dtype), q(w, dtype), None, padding=1)
@@ -96,6 +106,13 @@ def test_conv_strided_slices_and_accumulate(dtype):
     exp = base.float().clone(); exp[..., 32:96] += ref.permute(0, 2, 3, 1)
     assert rel_err(got[..., 32:96], q(exp[..., 32:96], dtype)) < TOL[dtype]
     assert torch.equal(got[..., :32], base.float()[..., :32]) and torch.equal(got[..., 96:], base.float()[..., 96:])
+    if dtype != torch.float32:                                  # ReLU in the epilogue (bit 1), with a bias
+        b = torch.randn(co, generator=g)
+        y = torch.empty(n, h, w_, co, dtype=dtype, device=DEV)
+        lib.mi355_conv2d_igemm(xin.data_ptr() + 64 * es, wf, b.to(DEV), y, n, h, w_, ci, 96, h, w_, co, co, 3, 3, 1, 1, -1, 1, 0, 2, None,
+                               DTYPE_CODE[dtype])
+        torch.cuda.synchronize()
+        assert rel_err(from_nhwc(y), torch.relu(ref + b.view(1, -1, 1, 1))) < TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -146,7 +163,7 @@ WG_CASES = [  # N, Ci, H, W, Co, K, stride, pad, up
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("shape", [(2, 128, 8, 16, 64), (1, 64, 16, 16, 128), (2, 64, 4, 16, 64)])      # n, co, h, w (input grid), ci
+@pytest.mark.parametrize("shape", [(2, 128, 8, 16, 64), (1, 64, 16, 16, 128), (2, 64, 4, 16, 64), (2, 64, 16, 32, 128)])      # n, co, h, w (input grid), ci
 def test_upsampled_conv_dgrad_with_fused_2x2_sum(shape, dtype):
     """conv(Upsample(x2)(x)) (AttentionUNet.py:19-20): the data gradient on the up-sampled grid is summed over 2x2 groups
     in the kernel epilogue (accumulate bit 2) — against autograd through F.interpolate, plain and accumulating."""
@@ -204,7 +221,7 @@ def test_conv_wgrad(case, dtype):
         assert rel_err(dw.cpu(), 2 * ref) < TOL[dtype]
 
 
-@pytest.mark.parametrize("case", [(2, 64, 16, 32, 128, 3, 1, 1, 0), (2, 96, 16, 16, 64, 3, 1, 1, 0), (3, 64, 9, 7, 64, 1, 1, 0, 0),
+@pytest.mark.parametrize("case", [(2, 64, 16, 32, 128, 3, 1, 1, 0), (2, 96, 32, 64, 64, 3, 1, 1, 0), (2, 96, 16, 16, 64, 3, 1, 1, 0), (3, 64, 9, 7, 64, 1, 1, 0, 0),
                                   (2, 64, 8, 16, 128, 3, 1, 1, 1), (1, 32, 5, 5, 128, 3, 2, 1, 0)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_conv_fused_bn_statistics(case, dtype):

@@ -583,7 +583,7 @@ def test_torchvision_layout_resnets_match_oracle_fp32(name):
     l64, o64, g64 = otrain.forward_backward(name, sd64, x.double(), y, False)
     _, o32, g32 = otrain.forward_backward(name, {k: v.clone() for k, v in sd.items()}, x, y, False)
     assert _rel(out.detach().cpu().numpy(), o64.numpy()) < 1e-4
-    assert abs(float(loss.detach()) - l64) < 1e-5 * max(1.0, abs(l64))
+    assert abs(float(loss.detach()) - l64) < 1e-4 * max(1.0, abs(l64))
     params = dict(m.named_parameters())
     gmax = max(float(v.abs().max()) for v in g64.values())
     e_gpu, e_cpu = [], []

@@ -1,0 +1,50 @@
+"""CPU: the kink record / replay of the oracle (oracle/nets.py::Kinks).  The gradients of these ReLU / max-pool networks are
+discontinuous: fp32 and fp64 evaluations disagree on a handful of ReLU masks (pre-activations within rounding distance of zero)
+and therefore on every gradient by ~1e-3, whatever the implementation.  With the fp32 evaluation's masks replayed inside the
+fp64 evaluation both compute the same smooth function and agree to rounding accuracy — the basis of the sharp whole-model
+gradient checks of tests/test_gpu_kinks.py."""
+import numpy as np
+import torch
+
+from oracle import nets
+from oracle import train as otrain
+
+
+def _grads(name, sd, x, y, dtype, mode=None, kinks=None):
+    s = {k: (v.to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    if mode:
+        nets.Kinks.start(mode, *(kinks or ()))
+    try:
+        loss, out, g = otrain.forward_backward(name, s, x.to(dtype), y.to(dtype), True)
+    finally:
+        relu, pool, used = nets.Kinks.stop()
+    return loss, out, g, (relu, pool), used
+
+
+def _errs(g, ref):
+    gmax = max(float(v.abs().max()) for v in ref.values())
+    out = []
+    for k, r in ref.items():
+        sc = float(r.abs().max())
+        if sc >= 1e-6 * gmax:
+            out.append(float((g[k].double() - r).abs().max()) / sc)
+    return np.array(out)
+
+
+def test_replayed_masks_make_fp32_and_fp64_gradients_agree():
+    name = "AttentionUNet"
+    sd = nets.closed_form_state(name)
+    x, y = otrain.closed_form_input(2, 32)
+    _, o32, g32, kinks, _ = _grads(name, sd, x, y, torch.float32, "record")
+    assert len(kinks[0]) == 26 and len(kinks[1]) == 4            # 18 block + 4 up-conv + 4 gate ReLUs, 4 max-pools
+    _, o64, g64, _, _ = _grads(name, sd, x, y, torch.float64)
+    _, o64r, g64r, _, used = _grads(name, sd, x, y, torch.float64, "replay", kinks)
+    assert used == (26, 4)
+    plain, replay = _errs(g32, g64), _errs(g32, g64r)
+    assert np.median(replay) < 3e-5 and replay.max() < 3e-4, (np.median(replay), replay.max())
+    assert np.median(replay) <= np.median(plain)                 # (plain: 4e-4 on this fixture — a few flipped masks)
+    assert float((o32.double() - o64r).abs().max() / o64r.abs().max()) < 1e-4
+    # replaying an evaluation's own masks reproduces it
+    _, _, g64s, kinks64, _ = _grads(name, sd, x, y, torch.float64, "record")
+    _, _, g64t, _, _ = _grads(name, sd, x, y, torch.float64, "replay", kinks64)
+    assert _errs(g64t, g64s).max() < 1e-12

@@ -259,7 +259,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     final_loss = float(loss.detach())
-    log(f"timed region done: {elapsed / args.steps * 1e3:.2f} ms/step (host issue time {issue_ms:.2f} ms/step)")
+    # host cost of ISSUING one step, measured on an empty queue (over many back-to-back steps the runtime's bounded launch queue
+    # makes the host wait for the GPU, so `issue_ms` above converges to the GPU time and says nothing about the host)
+    one = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        runner()
+        one.append((time.perf_counter() - t1) * 1e3)
+    torch.cuda.synchronize()
+    issue_one_ms = min(one)
+    log(f"timed region done: {elapsed / args.steps * 1e3:.2f} ms/step (host time to issue ONE step on an idle queue "
+        f"{issue_one_ms:.2f} ms; {issue_ms:.2f} ms/step over the back-to-back region, bounded by the launch queue)")
 
     result = None
     if rank == 0:
@@ -276,7 +287,8 @@ def main():
                                    f"bs={args.batch}/GPU, NHWC {args.dtype} activations, fp32 master weights",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": bool(args.graph),
                        "wgrad_side_stream": os.environ.get("MI355_SIDE_STREAM", "1") != "0",
-                       "final_loss": round(final_loss, 5)},
+                       "final_loss": round(final_loss, 5), "host_issue_ms_per_step": round(issue_one_ms, 3),
+                       "plan_replay": "C (mi355_plan_run)" if os.environ.get("MI355_PLAN_C", "1") != "0" else "python loop"},
         }
         if args.model == "AttentionUNet":         # (SURVEY.md 8d gives the per-image FLOPs of this model only)
             step_tflops = TRAIN_GFLOP_PER_IMG * (args.size / 256) ** 2 * value / world / 1e3

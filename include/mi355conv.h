@@ -286,6 +286,16 @@ int mi355_warp_u8(const uint8_t* src, int N, int Hs, int Ws, int C, const float*
 int mi355_normalize_u8(const uint8_t* src, int N, int H, int W, int C, const float* bc, const float* mean, const float* stdv,
                        float* out, mi355_stream_t s);
 
+/* ---- PNG files -> uint8 batch on the host (utils/dataset.py:55,101-102: PIL Image.open(path).convert("RGB" | "L")) ----------- */
+/* Header fields of a PNG held in memory.  MI355_ERR_UNSUPPORTED (fields still filled) for 16-bit samples / Adam7 interlacing. */
+int mi355_png_info(const uint8_t* file, long long nbytes, int* W, int* H, int* color_type, int* bit_depth);
+/* out[H][W][channels] uint8 = what PIL yields for .convert("RGB") (channels = 3) or .convert("L") (channels = 1): gray replicated,
+ * alpha dropped, palette looked up, 1/2/4-bit gray scaled to 0..255, RGB -> L by (19595 R + 38470 G + 7471 B + 0x8000) >> 16. */
+int mi355_png_decode(const uint8_t* file, long long nbytes, int channels, uint8_t* out, long long out_bytes);
+/* n files of one size W x H into out + i * stride (a pinned host batch), decoded by `threads` native threads. */
+int mi355_png_decode_batch(const uint8_t* const* files, const long long* nbytes, int n, int channels, uint8_t* out,
+                           long long stride, int W, int H, int threads);
+
 /* ---- joint inference pipeline glue (utils/pipeline.py:324-357 classify, 359-418 process_image) ---------- */
 /* pred[b] = argmax_c logits[b][c] (first maximum), conf[b] = 100 * max softmax; kept[0..n_kept) = the batch indices
  * with pred == keep_class, in order.  B <= 1024. */

@@ -536,8 +536,10 @@ static IgemmVariant pick_variant(int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
   const bool is3x3s1 = KH == 3 && KW == 3 && mul == 1 && div == 1 && Ho == Hlog && Wo == Wlog &&
                        ((kmul == 1 && off == -1) || (kmul == -1 && off == 1 && !up));
   if (is3x3s1 && Co % 64 == 0) {
-    // 16 x 32 tiles, two phase-shifted halves per workgroup (conv3x3_halo_pp.hpp); MI355_HALO_PP=0: the 4-wave kernel (A/B)
-    static const int use_pp = getenv("MI355_HALO_PP") ? atoi(getenv("MI355_HALO_PP")) : 1;
+    // MI355_HALO_PP=1: 16 x 32 tiles, two phase-shifted halves per 512-thread workgroup (conv3x3_halo_pp.hpp).  Measured
+    // (profiles/r02a_*): +1-3 % on the 32x32 layers with Ci >= 512, -10-15 % on the 256x256 layers (one workgroup per CU
+    // exposes every tile's prologue and epilogue) -> the 4-wave kernel below stays the default; the variant is kept selectable.
+    static const int use_pp = getenv("MI355_HALO_PP") ? atoi(getenv("MI355_HALO_PP")) : 0;
     if (use_pp && Wo % 32 == 0 && Ho % 16 == 0) return IG_HALO_PP;
     if (Wo % 32 == 0 && Ho % 8 == 0) return IG_HALO_8x32;
     if (Wo % 16 == 0 && Ho % 16 == 0) return IG_HALO_16x16;

@@ -570,7 +570,7 @@ class Builder:
         if os.environ.get("MI355_IGEMM_VARIANT") == "0":            # A/B switch of the launcher: register-staged generic kernel
             return f"conv_igemm_kernel<bf16,{bn},{64 if ci % 64 == 0 else 32}>"
         if k == 3 and s == 1 and co % 64 == 0 and not (dgrad and up):
-            if Wo % 32 == 0 and Ho % 16 == 0 and os.environ.get("MI355_HALO_PP", "1") != "0":
+            if Wo % 32 == 0 and Ho % 16 == 0 and os.environ.get("MI355_HALO_PP", "0") == "1":
                 return "conv3x3_halo_pp_kernel"
             if Wo % 32 == 0 and Ho % 8 == 0:
                 return "conv3x3_halo_rw_kernel<8,32>"

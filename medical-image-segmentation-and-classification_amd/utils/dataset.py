@@ -1,0 +1,138 @@
+"""Datasets of the MI355X path — same class names, constructor arguments and sample lists as the reference's
+utils/dataset.py (``ClassificationDataset`` :24-67, ``SegmentationDataset`` :70-137: ``dataset/splits/{split}.csv`` rows
+``id, class`` -> ``{root}/{class}/images/{id}.png`` [+ ``masks/{id}.png``], files that do not exist are skipped), feeding the GPU
+input pipeline instead of per-sample Albumentations in DataLoader workers:
+
+    ds = SegmentationDataset("dataset", SegBatchTransform(256, train=True), split="train")
+    for x, y in GpuBatchLoader(ds, batch_size=8, shuffle=True):      # x [B,3,256,256] float32, y [B,1,256,256] on the GPU
+        ...                                                             # exactly what helpers.train() consumes
+
+PNG files are decoded by native threads (csrc/png_decode.cpp: PIL's ``Image.open(p).convert("RGB" / "L")`` semantics, pinned
+bit-exactly by tests/test_png_decode.py) into ONE pinned uint8 batch, copied to HBM, and resized / augmented / normalised
+there (utils/gpu_transforms.py).  ``dataset[i]`` still works sample by sample (a batch of one) for code that indexes."""
+from __future__ import annotations
+
+import csv
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+from mi355.lib import lib
+
+CLASSES = ["COVID", "Healthy", "Non-COVID"]          # utils/pipeline.py:22, imported by the reference's dataset.py:16
+
+
+def _rows(root, split):
+    path = os.path.join(root, "splits", f"{split}.csv")
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"Split file not found: {path}")
+    with open(path, newline="") as f:
+        return [(r["id"], r["class"]) for r in csv.DictReader(f)]
+
+
+def read_files(paths):
+    out = []
+    for p in paths:
+        with open(p, "rb") as f:
+            out.append(np.frombuffer(f.read(), dtype=np.uint8))
+    return out
+
+
+def png_size(buf):
+    w, h = ctypes.c_int(), ctypes.c_int()
+    rc = lib.raw("mi355_png_info")(buf.ctypes.data, buf.size, ctypes.byref(w), ctypes.byref(h), None, None)
+    if rc:
+        raise RuntimeError(f"PNG header: {lib.raw('mi355_last_error')().decode()}")
+    return h.value, w.value
+
+
+def decode_batch(bufs, channels, threads=8, pin=True):
+    """PNG byte buffers of ONE size -> uint8 tensor [N, H, W, channels] in (pinned) host memory."""
+    n = len(bufs)
+    h, w = png_size(bufs[0])
+    out = torch.empty((n, h, w, channels), dtype=torch.uint8, pin_memory=pin and torch.cuda.is_available())
+    ptrs = (ctypes.c_void_p * n)(*[b.ctypes.data for b in bufs])
+    sizes = (ctypes.c_longlong * n)(*[b.size for b in bufs])
+    rc = lib.raw("mi355_png_decode_batch")(ptrs, sizes, n, channels, out.data_ptr(), h * w * channels, w, h, threads)
+    if rc:
+        raise RuntimeError(f"PNG decode: {lib.raw('mi355_last_error')().decode()}")
+    return out
+
+
+class ClassificationDataset:
+    def __init__(self, root, transform, split="train"):
+        self.root, self.transform = root, transform
+        self.samples = []
+        for img_id, cls in _rows(root, split):
+            p = os.path.join(root, cls, "images", f"{img_id}.png")
+            if os.path.exists(p):
+                self.samples.append((p, CLASSES.index(cls)))
+
+    def __len__(self):
+        return len(self.samples)
+
+    def load_batch(self, idxs, threads=8):
+        paths = [self.samples[i][0] for i in idxs]
+        labels = torch.tensor([self.samples[i][1] for i in idxs], dtype=torch.int64)
+        return decode_batch(read_files(paths), 3, threads), labels
+
+    def __getitem__(self, idx):
+        img, label = self.load_batch([idx], 1)
+        if self.transform is None:
+            return img[0].permute(2, 0, 1), int(label[0])                 # ToTensorV2 of the raw image (dataset.py:62)
+        return self.transform(img)[0], int(label[0])
+
+
+class SegmentationDataset:
+    def __init__(self, root, transform, split="train"):
+        self.root, self.transform = root, transform
+        self.pairs = []
+        for img_id, cls in _rows(root, split):
+            ip = os.path.join(root, cls, "images", f"{img_id}.png")
+            mp = os.path.join(root, cls, "masks", f"{img_id}.png")
+            if os.path.exists(ip) and os.path.exists(mp):
+                self.pairs.append((ip, mp))
+
+    def __len__(self):
+        return len(self.pairs)
+
+    def load_batch(self, idxs, threads=8):
+        imgs = decode_batch(read_files([self.pairs[i][0] for i in idxs]), 3, threads)
+        masks = decode_batch(read_files([self.pairs[i][1] for i in idxs]), 1, threads)
+        return imgs, masks[..., 0]
+
+    def __getitem__(self, idx):
+        img, mask = self.load_batch([idx], 1)
+        if self.transform is None:
+            return img[0].permute(2, 0, 1), mask[0][None].float() / 255.0   # dataset.py:129-133
+        x, y = self.transform(img, mask)
+        return x[0], y[0]
+
+
+class GpuBatchLoader:
+    """DataLoader stand-in for the two datasets above: yields device batches; ``len(loader)`` / ``loader.dataset`` as
+    helpers.train() uses them (helpers.py:317-342, 365)."""
+
+    def __init__(self, dataset, batch_size, shuffle=False, drop_last=False, seed=0, threads=8, device="cuda"):
+        self.dataset, self.batch_size, self.shuffle, self.drop_last = dataset, int(batch_size), shuffle, drop_last
+        self.gen = torch.Generator().manual_seed(seed)
+        self.threads, self.device = threads, torch.device(device)
+
+    def __len__(self):
+        n = len(self.dataset)
+        return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
+
+    def __iter__(self):
+        n = len(self.dataset)
+        order = torch.randperm(n, generator=self.gen).tolist() if self.shuffle else list(range(n))
+        tf = self.dataset.transform
+        for b in range(len(self)):
+            idxs = order[b * self.batch_size:(b + 1) * self.batch_size]
+            if isinstance(self.dataset, SegmentationDataset):
+                imgs, masks = self.dataset.load_batch(idxs, self.threads)
+                yield tf(imgs.to(self.device, non_blocking=True), masks.to(self.device, non_blocking=True))
+            else:
+                imgs, labels = self.dataset.load_batch(idxs, self.threads)
+                yield tf(imgs.to(self.device, non_blocking=True)), labels.to(self.device, non_blocking=True)

@@ -69,9 +69,11 @@ class SegBatchTransform:
         lib.mi355_warp_u8(images, n, hs, ws, 3, m0, img, s, s, 0, 0)
         msk = None
         if masks is not None:
-            masks = masks.to(self.device).contiguous().view(n, hs, ws, 1)
+            hm, wm = masks.shape[1], masks.shape[2]         # (the dataset's masks are 256x256 next to 299x299 images: A.Resize maps each)
+            masks = masks.to(self.device).contiguous().view(n, hm, wm, 1)
+            mm = m0 if (hm, wm) == (hs, ws) else torch.tensor([resize_matrix(hm, wm, s, s)] * n, dtype=torch.float32, device=self.device)
             msk = torch.empty(n, s, s, 1, dtype=torch.uint8, device=self.device)
-            lib.mi355_warp_u8(masks, n, hs, ws, 1, m0, msk, s, s, 1, 0)
+            lib.mi355_warp_u8(masks, n, hm, wm, 1, mm, msk, s, s, 1, 0)
         return img, msk
 
     @torch.no_grad()

@@ -252,6 +252,56 @@ def cls_metric_fixture():
     print("cls_metrics:", len(cases), "cases")
 
 
+def png_fixture():
+    """PNG byte streams written by PIL and the arrays PIL's ``Image.open(...).convert("RGB" / "L")`` returns for them — the
+    reference's decode path (utils/dataset.py:55,101-102).  Pillow is a third-party dependency of the reference
+    (requirements.txt: pillow==10.4.0; this container: see PIL.__version__ in the file), not reference code."""
+    import io
+    import PIL
+    from PIL import Image
+    g = np.random.RandomState(11)
+    yy, xx = np.mgrid[0:299, 0:299]
+    xray = (127 + 90 * np.sin(xx / 37.0) * np.cos(yy / 53.0) + g.randint(-3, 4, (299, 299))).clip(0, 255).astype(np.uint8)
+    mask = ((((yy - 128) / 90.0) ** 2 + ((xx - 120) / 70.0) ** 2) <= 1).astype(np.uint8)[:256, :256] * 255
+    pal = Image.fromarray((g.randint(0, 256, (45, 67)) % 23).astype(np.uint8), "P")
+    pal.putpalette(g.randint(0, 256, 3 * 23).astype(np.uint8).tobytes())
+    pal4 = Image.fromarray((g.randint(0, 256, (20, 21)) % 11).astype(np.uint8), "P")
+    pal4.putpalette(g.randint(0, 256, 3 * 11).astype(np.uint8).tobytes())
+    cases = {
+        "gray_299": Image.fromarray(xray, "L"),                                   # what the dataset's images look like
+        "mask_256": Image.fromarray(mask, "L"),                                   # ... and its masks
+        "rgb_odd": Image.fromarray(g.randint(0, 256, (31, 45, 3)).astype(np.uint8), "RGB"),
+        "rgba": Image.fromarray(g.randint(0, 256, (17, 19, 4)).astype(np.uint8), "RGBA"),
+        "gray_alpha": Image.fromarray(g.randint(0, 256, (13, 29, 2)).astype(np.uint8), "LA"),
+        "palette": pal,
+        "palette_small": pal4,                                                     # PIL writes 4-bit indices
+        "bilevel": Image.fromarray((g.randint(0, 2, (23, 37)) * 255).astype(np.uint8)).convert("1"),
+        "smooth_rgb": Image.fromarray(np.stack([xray[:64, :80], xray[10:74, 5:85], 255 - xray[:64, :80]], -1), "RGB"),
+        "one_pixel": Image.fromarray(np.array([[200]], dtype=np.uint8), "L"),
+        "one_row": Image.fromarray(g.randint(0, 256, (1, 70, 3)).astype(np.uint8), "RGB"),
+        "one_col": Image.fromarray(g.randint(0, 256, (70, 1)).astype(np.uint8), "L"),
+    }
+    rec = {"pillow": np.array(PIL.__version__)}
+    names = []
+    for tag, im in cases.items():
+        for lvl in ((6,) if im.size[0] * im.size[1] > 10000 else (6, 1)):        # (large images once: fixture size)
+            name = tag if lvl == 6 else tag + "_fast"
+            bio = io.BytesIO()
+            im.save(bio, format="PNG", compress_level=lvl)
+            data = bio.getvalue()
+            ref = Image.open(io.BytesIO(data))
+            rec[f"{name}/png"] = np.frombuffer(data, dtype=np.uint8)
+            rec[f"{name}/rgb"] = np.array(ref.convert("RGB"))
+            rec[f"{name}/l"] = np.array(ref.convert("L"))
+            names.append(name)
+    bio = io.BytesIO()
+    Image.fromarray((xray[:32, :32].astype(np.uint16) * 257), "I;16").save(bio, format="PNG")
+    rec["gray16_unsupported/png"] = np.frombuffer(bio.getvalue(), dtype=np.uint8)
+    rec["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "png_cases.npz"), **rec)
+    print("png_cases:", len(names), "streams, pillow", PIL.__version__)
+
+
 def main(only=()):
     os.makedirs(OUT, exist_ok=True)
     C = _ref_classes()
@@ -260,6 +310,7 @@ def main(only=()):
         "blocks": lambda: block_fixtures(C),
         "metrics": lambda: metric_fixture(H),
         "cls_metrics": cls_metric_fixture,
+        "png": png_fixture,
         "AttentionUNet": lambda: model_fixture("AttentionUNet", C["AttentionUNet"], 64, True),
         "R2AttU_Net": lambda: model_fixture("R2AttU_Net", C["R2AttU_Net"], 32, True),
         "R2U_Net": lambda: model_fixture("R2U_Net", C["R2U_Net"], 32, True),

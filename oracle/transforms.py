@@ -80,14 +80,16 @@ def val_seg_sample(img, mask, size=256):
     """val_seg_transform (trainer.py:100-112) + dataset.py:120-126."""
     hs, ws, _ = img.shape
     m = resize_matrix(hs, ws, size, size)
-    return normalize_u8(warp_u8(img, m, size, size)), normalize_u8(warp_u8(mask, m, size, size, nearest=True), mean=None)
+    mm = resize_matrix(mask.shape[0], mask.shape[1], size, size)      # (A.Resize maps image and mask from their own extents)
+    return normalize_u8(warp_u8(img, m, size, size)), normalize_u8(warp_u8(mask, mm, size, size, nearest=True), mean=None)
 
 
 def train_seg_sample(img, mask, angle, scale, dx, dy, hflip, alpha, beta, size=256):
     """train_seg_transform (trainer.py:83-98) with its random draws given explicitly."""
     hs, ws, _ = img.shape
     m0 = resize_matrix(hs, ws, size, size)
-    i1, k1 = warp_u8(img, m0, size, size), warp_u8(mask, m0, size, size, nearest=True)
+    mm = resize_matrix(mask.shape[0], mask.shape[1], size, size)
+    i1, k1 = warp_u8(img, m0, size, size), warp_u8(mask, mm, size, size, nearest=True)
     m1 = shift_scale_rotate_matrix(size, size, angle, scale, dx, dy, hflip)
     i2, k2 = warp_u8(i1, m1, size, size, reflect=True), warp_u8(k1, m1, size, size, nearest=True, reflect=True)
     return normalize_u8(i2, alpha, beta), normalize_u8(k2, mean=None)

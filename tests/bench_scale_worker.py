@@ -1,7 +1,7 @@
-"""Helper process of tests/test_gpu_bench_scale.py (not a test): one Attention U-Net evaluation + one train step at the
-BENCHMARK shape (256x256, batch 32) on the HIP path, results written to an .npz.  A process of its own because the kernel
-selection switches (MI355_WGRAD_HALO, MI355_IGEMM_VARIANT) are read once per process.
-usage: python bench_scale_worker.py {bf16|fp32} OUT.npz"""
+"""Helper process of tests/test_gpu_bench_scale.py (not a test): Attention U-Net at the BENCHMARK shape (256x256, batch 32) on
+the HIP path in fp32, fp16 and bf16 from the same weights and batch — one evaluation and one train step each — and the
+differences of the 2-byte runs from the fp32 run, layer by layer.  A process of its own because the kernel selection switches
+(MI355_WGRAD_HALO, MI355_IGEMM_VARIANT) are read once per process.      usage: python bench_scale_worker.py OUT.npz"""
 import os
 import sys
 
@@ -23,32 +23,56 @@ def he_state():
     return sd
 
 
-def main():
+def l2rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm())
+
+
+def run(dtype, x, y):
     from mi355 import nn as mnn
     from models.segmentation_models.AttentionUNet import AttentionUNet
-    dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[sys.argv[1]]
-    dev = "cuda:0"
     m = AttentionUNet()
     m.load_state_dict(he_state())
     m.compute_dtype = dtype
-    m = m.to(dev)
-    x, y = bench.make_batch(32, 256, seed=0, device=dev)
+    m = m.to("cuda:0")
     m.eval()
     with torch.no_grad():
-        ev = m(x).float().cpu().numpy()
+        ev = m(x).float()
     m.train()
     out = m(x)
     loss = mnn.BCEWithLogitsLoss()(out, y)
     loss.backward()
     torch.cuda.synchronize()
-    names = [k for k, _ in m.named_parameters()]
-    gn = np.array([float(p.grad.double().norm()) for _, p in m.named_parameters()])
-    fg = m.engine.flat_g
-    plan = [p for p in m.engine.plans.values() if p.training][0]
-    tags = sorted({l.tag for l in plan.fwd + plan.bwd if l.tag})
-    np.savez(sys.argv[2], eval_first=ev[0], eval_last=ev[31], logits=out.detach().float().cpu().numpy(), loss=float(loss.detach()),
-             grad_norm=gn, names=np.array(names), grad_sample=fg[::997].cpu().numpy(), grad_total=float(fg.double().norm()),
-             tags=np.array(tags), finite=bool(torch.isfinite(fg).all()))
+    plan = out._mi355_plan
+    acts = [a[1].torch_view().float().clone() for a in plan.acts if a[0] == "relu"]
+    return {"eval": ev, "logits": out.detach().float().clone(), "loss": float(loss.detach()), "acts": acts,
+            "grad_norm": np.array([float(p.grad.double().norm()) for _, p in m.named_parameters()]),
+            "flat_g": m.engine.flat_g.clone(), "tags": sorted({l.tag for l in plan.fwd + plan.bwd if l.tag})}
+
+
+def main():
+    x, y = bench.make_batch(32, 256, seed=0, device="cuda:0")
+    ref = run(torch.float32, x, y)
+    rec = {"eval_first": ref["eval"][0].cpu().numpy(), "eval_last": ref["eval"][31].cpu().numpy(), "loss_fp32": ref["loss"],
+           "grad_norm_fp32": ref["grad_norm"], "finite_fp32": bool(torch.isfinite(ref["flat_g"]).all())}
+    for tag, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+        r = run(dt, x, y)
+        rec[f"tags_{tag}"] = np.array(r["tags"])
+        rec[f"loss_{tag}"] = r["loss"]
+        rec[f"eval_err_{tag}"] = l2rel(r["eval"], ref["eval"])
+        rec[f"logit_err_{tag}"] = l2rel(r["logits"], ref["logits"])
+        rec[f"act_err_{tag}"] = np.array([l2rel(a, b) for a, b in zip(r["acts"], ref["acts"])])
+        rec[f"grad_norm_{tag}"] = r["grad_norm"]
+        g, g0 = r["flat_g"].double(), ref["flat_g"].double()
+        rec[f"grad_cos_{tag}"] = float((g * g0).sum() / (g.norm() * g0.norm()))
+        rec[f"grad_total_{tag}"] = float(g.norm() / g0.norm())
+        rec[f"finite_{tag}"] = bool(torch.isfinite(r["flat_g"]).all())
+        rec[f"grad_sample_{tag}"] = r["flat_g"][::997].cpu().numpy()
+        rec[f"logits_{tag}"] = r["logits"][:2].cpu().numpy()
+        rec[f"mask_agree_{tag}"] = float(((r["logits"] > 0) == (ref["logits"] > 0)).float().mean())
+    np.savez(sys.argv[1], **rec)
+    for k, v in rec.items():
+        if np.ndim(v) == 0 or (np.ndim(v) == 1 and len(v) <= 30 and v.dtype.kind == "f"):
+            print(k, v)
 
 
 if __name__ == "__main__":

@@ -43,3 +43,35 @@ def rel_err(a, b):
 def q(x, dtype):
     """Round-trip through the storage dtype (what the kernel actually sees)."""
     return x.to(dtype).float()
+
+
+def gpu_kinks(plan):
+    """ReLU masks (NCHW bool) and max-pool arg-max indices (torch layout) of the forward the plan just ran — the decisions the
+    GPU actually took, read back from the plan's activation buffers (Plan.acts), for replay inside the oracle (oracle.nets.Kinks)."""
+    import torch.nn.functional as F
+    relu, pool = [], []
+    for a in plan.acts:
+        if a[0] == "relu":
+            relu.append((a[1].torch_view().float() > 0).permute(0, 3, 1, 2).contiguous().cpu())
+        elif a[0] == "relu_pre":                  # recurrent block: only x + relu(.) is stored; the mask is that of scale * y + shift
+            y, sc, sh = a[1], a[2], a[3]
+            v = torch.addcmul(sh[: y.C].view(1, 1, 1, -1), y.torch_view().float(), sc[: y.C].view(1, 1, 1, -1))
+            relu.append((v > 0).permute(0, 3, 1, 2).contiguous().cpu())
+        elif a[0] == "pool":
+            x, k, s, p = a[1], a[3], a[4], a[5]
+            xv = x.torch_view().float().permute(0, 3, 1, 2).contiguous().cpu()
+            pool.append(F.max_pool2d(xv, k, s, p, return_indices=True)[1])          # first maximum wins, as in the kernel
+    return relu, pool
+
+
+def replayed_oracle(name, sd, x, y, relu, pool, seg=True, **net_kw):
+    """fp64 oracle forward + backward with the given kink decisions replayed -> (loss, logits, grads)."""
+    from oracle import nets, train as otrain
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    nets.Kinks.start("replay", relu, pool)
+    try:
+        res = otrain.forward_backward(name, sd64, x.double(), y.double() if seg else y, seg, **net_kw)
+    finally:
+        _, _, used = nets.Kinks.stop()
+    assert used == (len(relu), len(pool)), (used, len(relu), len(pool))
+    return res

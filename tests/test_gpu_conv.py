@@ -294,3 +294,18 @@ def test_pointwise_stream_kernel(nhw, ci, co, dtype):
     exp = base.float().clone(); exp[..., 32:32 + ci] += q(dref, dtype).permute(0, 2, 3, 1)
     assert rel_err(got[..., 32:32 + ci], q(exp[..., 32:32 + ci], dtype)) < TOL[dtype]
     assert torch.equal(got[..., :32], base.float()[..., :32]) and torch.equal(got[..., 32 + ci:], base.float()[..., 32 + ci:])
+
+
+def test_ping_pong_halo_variant_passes_the_same_cases():
+    """conv3x3_halo_pp.hpp (512-thread workgroups, load / matrix phases half a step apart) is opt-in (MI355_HALO_PP=1; it measured
+    +1-3 % on the deepest layers and -10-15 % on the 256x256 ones).  The switch is read once per process, so the forward / data
+    gradient / statistics / slice / ReLU / 2x2-sum cases of this file are re-run in a child process with the variant on."""
+    import os, subprocess, sys
+    if os.environ.get("MI355_HALO_PP") == "1":
+        pytest.skip("already the child process")
+    env = dict(os.environ, MI355_HALO_PP="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
+                        "fwd or dgrad or statistics or slices or upsampled"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    code = DTYPE_CODE[torch.bfloat16]
+    assert lib.mi355_conv2d_igemm_variant(32, 64, 64, 32, 64, 64, 3, 3, 1, 1, -1, 1, 0, code) == 2          # default: the 4-wave kernel

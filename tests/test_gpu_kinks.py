@@ -10,30 +10,12 @@ of the whole network must agree to rounding accuracy: 3e-4 of the tensor's maxim
 import numpy as np
 import pytest
 import torch
-import torch.nn.functional as F
-
+from gpu_util import gpu_kinks, replayed_oracle
 from oracle import nets
 from oracle import train as otrain
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-
-
-def gpu_kinks(plan):
-    """ReLU masks (NCHW bool) and max-pool arg-max indices (torch layout) of the forward the plan just ran."""
-    relu, pool = [], []
-    for a in plan.acts:
-        if a[0] == "relu":
-            relu.append((a[1].torch_view().float() > 0).permute(0, 3, 1, 2).contiguous().cpu())
-        elif a[0] == "relu_pre":                  # recurrent block: only x + relu(.) is stored; the mask is that of scale * y + shift
-            y, sc, sh = a[1], a[2], a[3]
-            v = torch.addcmul(sh[: y.C].view(1, 1, 1, -1), y.torch_view().float(), sc[: y.C].view(1, 1, 1, -1))
-            relu.append((v > 0).permute(0, 3, 1, 2).contiguous().cpu())
-        elif a[0] == "pool":
-            x, k, s, p = a[1], a[3], a[4], a[5]
-            xv = x.torch_view().float().permute(0, 3, 1, 2).contiguous().cpu()
-            pool.append(F.max_pool2d(xv, k, s, p, return_indices=True)[1])          # first maximum wins, as in the kernel
-    return relu, pool
 
 
 @pytest.mark.parametrize("name,bs,hw", [("AttentionUNet", 2, 64), ("R2AttU_Net", 2, 32), ("R2U_Net", 2, 32), ("AttentionUNet", 4, 128)])
@@ -51,13 +33,8 @@ def test_fp32_gradients_match_fp64_oracle_on_the_same_masks(name, bs, hw):
     loss.backward()
     torch.cuda.synchronize()
     relu, pool = gpu_kinks(out._mi355_plan)
-    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
-    nets.Kinks.start("replay", relu, pool)
-    try:
-        l64, o64, g64 = otrain.forward_backward(name, sd64, x.double(), y.double(), True)
-    finally:
-        _, _, used = nets.Kinks.stop()
-    assert used == (len(relu), len(pool)) and len(pool) == 4
+    l64, o64, g64 = replayed_oracle(name, sd, x, y, relu, pool)
+    assert len(pool) == 4
     assert float((out.detach().cpu().double() - o64).abs().max() / o64.abs().max()) < 1e-4
     assert abs(float(loss.detach()) - l64) < 1e-5
     gmax = max(float(v.abs().max()) for v in g64.values())

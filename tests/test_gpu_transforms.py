@@ -82,3 +82,32 @@ def test_cls_transforms_match_oracle(src):
         black = (0 - ot.IMAGENET_MEAN) / ot.IMAGENET_STD
         edge = v[:, 0, :] if src[0] < src[1] else v[:, :, 0]
         assert np.allclose(edge, black[:, None], atol=1e-6)
+
+
+def test_gpu_batch_loader_feeds_train_ready_batches(tmp_path):
+    """utils/dataset.py::GpuBatchLoader: PNG files -> native threaded decode -> pinned batch -> GPU transforms; the batches equal
+    the oracle's per-sample pipeline applied to PIL-decoded arrays (dataset.py:100-126 + trainer.py:98-112), images 299x299 with
+    256x256 masks as in the COVID-19 Radiography files."""
+    Image = pytest.importorskip("PIL.Image")
+    from test_dataset_cpu import make_tree
+    from utils.dataset import GpuBatchLoader, SegmentationDataset, ClassificationDataset
+    from utils.gpu_transforms import SegBatchTransform, ClsBatchTransform
+    root = str(tmp_path / "dataset")
+    make_tree(root, n=7)
+    ds = SegmentationDataset(root, SegBatchTransform(256, train=False, device=DEV), "train")
+    dl = GpuBatchLoader(ds, batch_size=4, shuffle=False, device=DEV)
+    assert len(dl) == 2 and len(dl.dataset) == 6
+    seen = 0
+    for x, y in dl:
+        assert x.is_cuda and x.shape[1:] == (3, 256, 256) and y.shape[1:] == (1, 256, 256)
+        for j in range(x.shape[0]):
+            ip, mp = ds.pairs[seen + j]
+            img = np.array(Image.open(ip).convert("RGB")); mask = np.array(Image.open(mp).convert("L"))
+            xr, yr = ot.val_seg_sample(img, mask[..., None], 256)
+            _close(x[j].cpu().numpy(), xr)
+            assert np.array_equal(y[j].cpu().numpy(), yr)
+        seen += x.shape[0]
+    assert seen == 6
+    cds = ClassificationDataset(root, ClsBatchTransform(256, train=False, device=DEV), "train")
+    got = [(x.shape, lab.tolist()) for x, lab in GpuBatchLoader(cds, batch_size=3, shuffle=True, seed=1, device=DEV)]
+    assert sum(len(l) for _, l in got) == 7 and all(s[1:] == (3, 256, 256) for s, _ in got)

@@ -40,8 +40,12 @@ def run(dtype, x, y):
     m.train()
     out = m(x)
     loss = mnn.BCEWithLogitsLoss()(out, y)
-    loss.backward()
+    # fp16 activation gradients need the reference's loss scaling (helpers.py:285,329): d loss / d logit = 1 / (32 * 65536) is
+    # below fp16's normal range.  A power of two, divided out of the flat gradient buffer below.
+    scale = 65536.0 if dtype == torch.float16 else 1.0
+    (loss * scale).backward()
     torch.cuda.synchronize()
+    m.engine.flat_g.mul_(1.0 / scale)
     plan = out._mi355_plan
     acts = [a[1].torch_view().float().clone() for a in plan.acts if a[0] == "relu"]
     return {"eval": ev, "logits": out.detach().float().clone(), "loss": float(loss.detach()), "acts": acts,

@@ -105,6 +105,29 @@ def pmc_traffic(kernel):
     return None, None
 
 
+def host_cores():
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota when the box hands out a share of
+    a larger host (a 1-GPU box owns 16 cores of the machine; running the oracle on every core the mask shows would only
+    oversubscribe that share)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                n = max(1, min(n, int(float(quota) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_model_name():
     try:
         for line in open("/proc/cpuinfo"):
@@ -121,12 +144,11 @@ def cpu_baseline(hw, bs=8, steps=3):
     segmentation batch size, trainer.py:160; the benchmark's 32 would take ~1 min per step), one warm-up + 3 timed steps,
     images/s = B / median step time; CPU model and core count reported."""
     from oracle import nets, train as otrain
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    # every core this process is entitled to: affinity mask / cgroup quota, and — the GPU pool's rule for a box that shows the
+    # whole host — the 16-core share that comes with each visible GPU (BENCH_CPU_THREADS overrides)
+    cores = min(host_cores(), 16 * max(1, torch.cuda.device_count()))
     if os.environ.get("BENCH_CPU_THREADS"):
-        cores = max(1, min(cores, int(os.environ["BENCH_CPU_THREADS"])))
+        cores = max(1, int(os.environ["BENCH_CPU_THREADS"]))
     torch.set_num_threads(cores)
     sd = nets.default_init_state("AttentionUNet", seed=0)
     x, y = otrain.synthetic_batch(bs, hw, seed=0)

@@ -11,7 +11,6 @@ from models.segmentation_models.AttentionUNet import AttentionUNet
 bs = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 x, _ = bench.make_batch(bs, 256, seed=0, device="cpu")
 sd = w.he_state()
-torch.set_num_threads(len(os.sched_getaffinity(0)))
 t0 = time.time()
 with torch.no_grad():
     ref = nets.attention_unet({k: v.clone() for k, v in sd.items()}, x, True).numpy()

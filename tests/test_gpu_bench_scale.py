@@ -52,7 +52,6 @@ def test_attention_unet_256_batch32(tmp_path):
     import bench
     x, _ = bench.make_batch(32, 256, seed=0, device="cpu")
     sd = w.he_state()
-    torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
     with torch.no_grad():
         for key, i in (("eval_first", 0), ("eval_last", 31)):
             r = nets.attention_unet({k: v.clone() for k, v in sd.items()}, x[i:i + 1], False)[0].numpy()

@@ -331,13 +331,12 @@ template <typename T, int TH, int TW>
 static int launch_halo_rw(const ConvArgs& a, hipStream_t s) {
   const int grid = a.N * (a.Ho / TH) * (a.Wo / TW) * (a.Co / 64);
   constexpr int lds_bytes = HaloRwCfg<TH, TW>::LDS_BYTES;
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_rw_kernel<T, TH, TW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       lds_bytes);
-    if (e != hipSuccess) MI355_FAIL((int)e, "conv3x3_halo_rw: cannot reserve %d B of LDS: %s", lds_bytes, hipGetErrorString(e));
-    configured = true;
-  }
+  // once per process and kernel variant; a function-local static is initialised exactly once even when two threads launch
+  // concurrently (forward on the main thread, backward on the autograd worker)
+  static const hipError_t configured = hipFuncSetAttribute((const void*)conv3x3_halo_rw_kernel<T, TH, TW>,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (configured != hipSuccess)
+    MI355_FAIL((int)configured, "conv3x3_halo_rw: cannot reserve %d B of LDS: %s", lds_bytes, hipGetErrorString(configured));
   hipLaunchKernelGGL((conv3x3_halo_rw_kernel<T, TH, TW>), dim3(grid), dim3(256), lds_bytes, s, a);
   MI355_LAUNCH_CHECK();
   return MI355_OK;

@@ -6,7 +6,15 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gl_void_t;
 static __device__ uint4 g_zero_page[16];   // 256 B of zeros: DMA source for padding rows (one copy per translation unit)
 
+// Counted wait: at most N of this wave's vector-memory operations (LDS-DMA pieces included) may still be in flight.
+// -DMI355_DMA_DRAIN (make drain -> libmi355conv_drain.so) turns EVERY counted wait into vmcnt(0): the conservative schedule the
+// hand-counted ones are A/B-ed against (tests/test_gpu_conv.py::test_counted_vmcnt_matches_drained_build compares the two builds
+// bit for bit — a wrong count shows up as a difference, not as a hang).
+#ifdef MI355_DMA_DRAIN
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#else
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+#endif
 
 // One 1-KiB LDS-DMA piece: lane i's 16 bytes at `gsrc` land at LDS byte address lds_base + 16*i.
 // Issued from inline asm ON PURPOSE: hipcc's waitcnt pass then does not know an LDS write is pending

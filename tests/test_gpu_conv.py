@@ -1,6 +1,7 @@
 """-m gpu: implicit-GEMM conv (forward, data gradient, ConvTranspose) through the C ABI vs
 torch CPU fp32 (F.conv2d / autograd).  Tolerances: fp32 1e-4 relative-to-max; bf16 / fp16 compare
 against the CPU result on operands rounded to that type: 2e-2 / 3e-3 relative-to-max (output rounding 2^-8 / 2^-11)."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -309,3 +310,28 @@ def test_ping_pong_halo_variant_passes_the_same_cases():
     assert r.returncode == 0, r.stdout[-3000:]
     code = DTYPE_CODE[torch.bfloat16]
     assert lib.mi355_conv2d_igemm_variant(32, 64, 64, 32, 64, 64, 3, 3, 1, 1, -1, 1, 0, code) == 2          # default: the 4-wave kernel
+
+
+def test_counted_vmcnt_matches_drained_build(tmp_path):
+    """The LDS-DMA kernels order their LDS reads behind the DMA writes with hand-COUNTED ``s_waitcnt vmcnt(N)`` (the DMA is issued from
+    inline asm so that hipcc does not drain the queue in front of every LDS read, dma.hpp).  ``libmi355conv_drain.so`` is the same
+    source with every counted wait replaced by vmcnt(0): forward, data-gradient and weight-gradient outputs of the two builds must
+    be identical bit for bit, and identical across repeated launches — a wrong count is a race, and a race shows up as a difference."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    so = os.path.join(os.path.dirname(here), "medical-image-segmentation-and-classification_amd", "mi355")
+    outs = {}
+    for tag, libname in (("counted", "libmi355conv.so"), ("drained", "libmi355conv_drain.so")):
+        path = os.path.join(so, libname)
+        assert os.path.exists(path), f"{libname} not built (make -C csrc)"
+        out = str(tmp_path / f"{tag}.npz")
+        r = subprocess.run([sys.executable, os.path.join(here, "conv_dump_worker.py"), out], env=dict(os.environ, MI355_LIB=path),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = np.load(out)
+    a, b = outs["counted"], outs["drained"]
+    assert set(a.files) == set(b.files) and len(a.files) >= 90
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
+        if k.endswith("0"):
+            assert np.array_equal(a[k], a[k[:-1] + "1"]) and np.array_equal(a[k], a[k[:-1] + "2"]), k

@@ -4,7 +4,7 @@ HIP bf16, HIP fp16 (+ loss scaling, helpers.py:285,323-336), HIP fp32, CPU fp32 
 BCEWithLogits, clip 1.0, AdamW wd 5e-4) —
 and compare the Dice of the binarised predictions (tester.py:114-134) on 32 held-out images.
 Bound: |Dice - Dice_oracle| <= 1e-3 (0..1 scale) for every GPU mode; final losses within 2 %.
-The same protocol runs R2AttU_Net (R2AttU_Net.py:88-158, config C4: bf16) for 12 steps against its fp32 oracle."""
+The same protocol runs R2AttU_Net (R2AttU_Net.py:88-158, config C4: bf16) for 20 steps against its fp32 oracle."""
 import pytest
 import torch
 
@@ -28,7 +28,7 @@ def _dice(logit, m):
 
 @pytest.mark.parametrize("name,steps,dtypes", [
     ("AttentionUNet", 40, (torch.float32, torch.bfloat16, torch.float16)),          # C3 (bf16) and C5's segmenter (fp16)
-    ("R2AttU_Net", 12, (torch.float32, torch.bfloat16)),                            # C4 (bf16)
+    ("R2AttU_Net", 20, (torch.float32, torch.bfloat16)),                            # C4 (bf16)
 ])
 def test_dice_after_training_matches_oracle(name, steps, dtypes):
     from mi355 import nn as mnn, optim as moptim, amp as mamp
@@ -78,6 +78,6 @@ def test_dice_after_training_matches_oracle(name, steps, dtypes):
         with torch.no_grad():
             d = _dice(m(xv.to(DEV)).float().cpu(), mv)       # train-mode BN, like the oracle evaluation above
         assert abs(d - ref_dice) <= 1e-3, (name, str(dtype), d, ref_dice)
-        # (R2AttU_Net: 12 steps through 108 shared-weight convolutions — the fp32 trajectories of two implementations drift
+        # (R2AttU_Net: 20 steps through 108 shared-weight convolutions — the fp32 trajectories of two implementations drift
         # 5 % apart in the final batch loss while the Dice of the held-out masks stays within 1e-3)
         assert abs(float(loss.detach()) - ref_loss) <= (0.02 if name == "AttentionUNet" else 0.10) * ref_loss, (name, str(dtype), float(loss.detach()), ref_loss)

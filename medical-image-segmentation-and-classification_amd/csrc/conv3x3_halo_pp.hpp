@@ -11,13 +11,16 @@
 //   tile        : 16 x 32 pixels (two 8 x 32 half tiles, one per half) x 64 output channels; the halves share the weight
 //                 stages (read once from L2 per 512 pixels instead of per 256) and one 18 x 34 halo patch per 32-channel slab
 //                 (re-fetch 1.20x instead of 1.33x of the tile's pixels)
-//   LDS         : 2 patch buffers x 39 KiB + 3 weight stages x 12 KiB = 114 KiB -> one workgroup per CU
+//   LDS         : 3 patch buffers x 39 KiB + 3 weight stages x 12 KiB = 153 KiB -> one workgroup per CU
 //   phases      : p = 0, 1, ...: half 0 runs R(s) at p = 2s and M(s) at p = 2s+1, half 1 runs R(s) at p = 2s+1 and M(s) at
 //                 p = 2s+2 (R = fragment reads + DMA issue of step s, M = its MFMAs); one s_barrier per phase
 //   DMA         : in R(s) a wave issues its share of the weight stage of step s+2 (ring slot (s+2) % 3, last read in R(s-1) of
-//                 half 1: one phase earlier) and, in the first step of a slab, of the NEXT slab's patch; counted vmcnt waits
-//                 at the end of every wave's (2s+1)-phase keep exactly the youngest issues in flight (same accounting as the
-//                 4-wave kernel: stage pieces are issued before patch pieces, so the patch may stay in flight for two steps)
+//                 half 1: one phase earlier) and 2 / 2 / 1 of its five pieces of the patch of the slab AFTER NEXT (buffer
+//                 (c+2) % 3, last read during slab c-1): at most four DMA issues per load phase — with all five patch pieces in
+//                 the first step of a slab that phase ran 1.5x the matrix phase and the kernel lost a quarter of its rate
+//                 (no-DMA ceiling 1885 TFLOP/s on 32x32x1024->512, 1482 with the unbalanced schedule).  Counted vmcnt waits at
+//                 the end of every wave's (2s+1)-phase keep exactly the youngest issues in flight: this step's stage and patch
+//                 pieces and the previous step's patch pieces (stage pieces are issued first)
 //   epilogue    : as conv3x3_halo.hpp (a lane owns four consecutive channels of a pixel; LDS-staged 16-byte row stores), one
 //                 C tile per half; half 0 stages its tile while half 1 runs its last matrix phase
 // Everything else (patch / slab images, swizzles, fragment maps, tap mirroring for the data gradient, x2 up-sampling in the
@@ -34,7 +37,8 @@ struct HaloPpCfg {
   static constexpr int PATCH_BYTES = P_INSTR * 1024;
   static constexpr int STAGE_BYTES = 3 * BN * 64;
   static constexpr int NS = 3;
-  static constexpr int RING = 2 * PATCH_BYTES + NS * STAGE_BYTES;
+  static constexpr int NPB = 3;                                          // patch buffers: slab c lives in buffer c % 3
+  static constexpr int RING = NPB * PATCH_BYTES + NS * STAGE_BYTES;
   static constexpr int C_BYTES = HTH * TW * (BN * 2 + 16);             // C tile of one half
   static constexpr int EPI_BYTES = 2 * C_BYTES + 2 * 2 * 2 * BN * 4;    // + statistics scratch [half][wm][q][BN]
   static constexpr int LDS_BYTES = RING > EPI_BYTES ? RING : EPI_BYTES;
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pp_kernel(const ConvArgs a) 
     p_off[i] = ok ? (unsigned)((((yy >> a.up) * a.Wi + (xx >> a.up)) * a.ldi + (slot ^ (((q >> 2) & 1) << 1)) * EPC) * 2) : 0xffffffffu;
   }
   unsigned char* const patch0 = lds;
-  unsigned char* const bring = lds + 2 * PATCH_BYTES;
+  unsigned char* const bring = lds + Cfg::NPB * PATCH_BYTES;
   auto issue_patch_piece = [&](int buf, int c0, int i) __attribute__((always_inline)) {
     unsigned o = p_off[i];
     asm volatile("" : "+v"(o));          // keep the 32-bit offset: a hoisted 64-bit address per piece costs 10 VGPRs (spills)
@@ -118,6 +122,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pp_kernel(const ConvArgs a) 
     }
   };
 
+  const int nC = a.Ci / BK;
+
   // ---- fragment geometry -----------------------------------------------------------------------------------------------
   const int q00 = (half * HTH + wm * RW) * PW + l16;
   const int brow0 = wn * WTN + l16;
@@ -130,42 +136,45 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pp_kernel(const ConvArgs a) 
   for (int nb = 0; nb < NB; ++nb)
     bias4[nb] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n0 + wn * WTN + nb * 16 + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nC = a.Ci / BK;
-  // prologue: patch of slab 0 and the stages of steps 0 and 1 (stage index == patch column)
-#pragma unroll
-  for (int i = 0; i < P_IT; ++i) issue_patch_piece(0, 0, i);
+  // prologue: patch of slab 0, the stages of steps 0 and 1 (stage index == patch column), then the patch of slab 1 (slab c + 2 is
+  // fetched during slab c, two or one pieces per wave and step: no load phase carries more than four DMA issues)
+  constexpr int NP0 = 2, NP1 = 2, NP2 = P_IT - 4;       // patch pieces a wave issues in the steps pw = 0, 1, 2 of a slab
+  static_assert(P_IT == 5, "piece schedule below is written for five patch pieces per wave and slab");
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>;
   using No = std::false_type;
   using Yes = std::true_type;
+#pragma unroll
+  for (int i = 0; i < P_IT; ++i) issue_patch_piece(0, 0, i);
   if (half == 0) {
     issue_stage(I0{}, 0, 0, 0);
     issue_stage(I0{}, 1, 1, 0);
-    wait_vmcnt<2>();                                             // all but stage 1
   } else {
     issue_stage(I1{}, 0, 0, 0);
     issue_stage(I1{}, 1, 1, 0);
-    wait_vmcnt<1>();
   }
+#pragma unroll
+  for (int i = 0; i < P_IT; ++i) issue_patch_piece(1, nC > 1 ? BK : 0, i);       // (one slab only: a dead buffer)
+  if (half == 0) wait_vmcnt<2 + P_IT>(); else wait_vmcnt<1 + P_IT>();            // all but stage 1 and the patch of slab 1
   __builtin_amdgcn_s_barrier();
 
   bf16x8 bfr[3][NB];
   bf16x8 afr[NPR][XB];
   // R(step): fragment reads of (slab chunk, patch column pw) + this wave's DMA issues: stage of step + 2, then (pw == 0) the next
   // slab's patch.
-  auto phase_r = [&](auto half_tag, int chunk, auto pw_tag, auto par_tag) __attribute__((always_inline)) {
+  auto phase_r = [&](auto half_tag, int chunk, auto pw_tag, auto pb_tag) __attribute__((always_inline)) {
     constexpr int pw = decltype(pw_tag)::value;
-    constexpr int par = decltype(par_tag)::value;
+    constexpr int pb = decltype(pb_tag)::value;        // chunk % 3: the patch buffer is a compile-time LDS offset
     constexpr int pw2 = (pw + 2) % 3;
     const int c2 = (pw == 0 ? chunk : chunk + 1);
     const int c0_stage = c2 < nC ? c2 * BK : -1;
-    const unsigned char* pa = patch0 + par * PATCH_BYTES;
-    const unsigned char* pb = bring + pw * STAGE;
+    const unsigned char* pa = patch0 + pb * PATCH_BYTES;
+    const unsigned char* pb_ = bring + pw * STAGE;
 #pragma unroll
     for (int ph = 0; ph < 3; ++ph)
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) bfr[ph][nb] = *reinterpret_cast<const bf16x8*>(pb + ph * SLAB + nb * 16 * PIXB + boff0);
+      for (int nb = 0; nb < NB; ++nb) bfr[ph][nb] = *reinterpret_cast<const bf16x8*>(pb_ + ph * SLAB + nb * 16 * PIXB + boff0);
     int qb = q00;
     asm volatile("" : "+v"(qb));                     // (opaque: the offsets must not be hoisted back into 18 loop-invariant registers)
 #pragma unroll
@@ -177,11 +186,11 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pp_kernel(const ConvArgs a) 
     }
     __builtin_amdgcn_sched_barrier(0);
     issue_stage(half_tag, pw2, pw2, c0_stage);
-    if constexpr (pw == 0) {
-      const bool next_patch = chunk + 1 < nC;
+    // this step's share of the patch of slab chunk + 2 (buffer (pb + 2) % 3: last read during slab chunk - 1)
+    constexpr int i0 = pw == 0 ? 0 : (pw == 1 ? NP0 : NP0 + NP1), i1 = pw == 0 ? NP0 : (pw == 1 ? NP0 + NP1 : P_IT);
+    const int cp = chunk + 2 < nC ? (chunk + 2) * BK : chunk * BK;        // (past the last slab: into a dead buffer)
 #pragma unroll
-      for (int i = 0; i < P_IT; ++i) issue_patch_piece(par ^ 1, next_patch ? (chunk + 1) * BK : chunk * BK, i);   // (last slab: a dead buffer)
-    }
+    for (int i = i0; i < i1; ++i) issue_patch_piece((pb + 2) % 3, cp, i);
     __builtin_amdgcn_sched_barrier(0);
   };
   // M: the 48 MFMAs of the step whose fragments sit in afr / bfr — nothing else in the stream
@@ -205,36 +214,39 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pp_kernel(const ConvArgs a) 
     }
     __builtin_amdgcn_sched_barrier(0);
   };
-  // end of a wave's (2s+1)-phase: everything but its youngest issues has landed (stage of step s+1 complete for the next phase)
-  auto wait_w = [&](auto half_tag, auto pw_tag) __attribute__((always_inline)) {
+  // end of a wave's (2s+1)-phase: the stage issued one step earlier has landed.  In flight may stay (issue order: stage pieces,
+  // then patch pieces): the previous step's patch pieces, this step's stage and patch pieces
+  auto wait_w = [&](auto half_tag, auto pw_tag, auto first_tag) __attribute__((always_inline)) {
     constexpr int pw = decltype(pw_tag)::value;
     constexpr int nS = decltype(half_tag)::value == 0 ? 2 : 1;
-    if constexpr (pw <= 1) wait_vmcnt<nS + P_IT>(); else wait_vmcnt<nS>();
+    constexpr int np = pw == 0 ? NP0 : (pw == 1 ? NP1 : NP2), np_prev = pw == 0 ? NP2 : (pw == 1 ? NP0 : NP1);
+    if constexpr (decltype(first_tag)::value) wait_vmcnt<nS + np + P_IT>();        // step 0: behind stage 1 sits the prologue's patch 1
+    else wait_vmcnt<nS + np + np_prev>();
   };
   // one iteration = the two phases 2s+1 and 2s+2 of step s = (chunk, pw):   half 0: M(s) | R(s+1)      half 1: R(s) | M(s)
-  auto iter = [&](auto half_tag, int chunk, auto pw_tag, auto par_tag, auto first_tag) __attribute__((always_inline)) {
+  auto iter = [&](auto half_tag, int chunk, auto pw_tag, auto pb_tag, auto first_tag) __attribute__((always_inline)) {
     constexpr int H = decltype(half_tag)::value;
     constexpr int pw = decltype(pw_tag)::value;
-    constexpr int par = decltype(par_tag)::value;
+    constexpr int pb = decltype(pb_tag)::value;
     constexpr int pwn = (pw + 1) % 3;
-    constexpr int parn = pw == 2 ? (par ^ 1) : par;
+    constexpr int pbn = pw == 2 ? (pb + 1) % 3 : pb;
     const int chunkn = pw == 2 ? chunk + 1 : chunk;
     const bool last = pw == 2 && chunk + 1 >= nC;
     if constexpr (H == 0) {
       phase_m(first_tag);
-      if (last) wait_vmcnt<0>(); else wait_w(half_tag, pw_tag);
+      if (last) wait_vmcnt<0>(); else wait_w(half_tag, pw_tag, first_tag);
       __builtin_amdgcn_s_barrier();
       if (!last) {
-        phase_r(half_tag, chunkn, std::integral_constant<int, pwn>{}, std::integral_constant<int, parn>{});
+        phase_r(half_tag, chunkn, std::integral_constant<int, pwn>{}, std::integral_constant<int, pbn>{});
         __builtin_amdgcn_s_barrier();
       }
     } else {
-      phase_r(half_tag, chunk, pw_tag, par_tag);
+      phase_r(half_tag, chunk, pw_tag, pb_tag);
       if (last) {
         wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // half 0 stages its C tile over the ring right after this barrier
       } else {
-        wait_w(half_tag, pw_tag);
+        wait_w(half_tag, pw_tag, first_tag);
       }
       __builtin_amdgcn_s_barrier();
       phase_m(first_tag);
@@ -247,7 +259,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pp_kernel(const ConvArgs a) 
     if constexpr (H == 0) phase_r(half_tag, 0, I0{}, I0{});          // phase 0: half 0 reads step 0, half 1 waits
     __builtin_amdgcn_s_barrier();
     iter(half_tag, 0, I0{}, I0{}, Yes{});
-    for (int chunk = 0;; chunk += 2) {
+    for (int chunk = 0;; chunk += 3) {           // (starts at column 1 so that only ONE extra step body exists: the FIRST one)
       iter(half_tag, chunk, I1{}, I0{}, No{});
       iter(half_tag, chunk, I2{}, I0{}, No{});
       if (chunk + 1 >= nC) break;
@@ -255,7 +267,11 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pp_kernel(const ConvArgs a) 
       iter(half_tag, chunk + 1, I1{}, I1{}, No{});
       iter(half_tag, chunk + 1, I2{}, I1{}, No{});
       if (chunk + 2 >= nC) break;
-      iter(half_tag, chunk + 2, I0{}, I0{}, No{});
+      iter(half_tag, chunk + 2, I0{}, I2{}, No{});
+      iter(half_tag, chunk + 2, I1{}, I2{}, No{});
+      iter(half_tag, chunk + 2, I2{}, I2{}, No{});
+      if (chunk + 3 >= nC) break;
+      iter(half_tag, chunk + 3, I0{}, I0{}, No{});
     }
   };
   if (half == 0) run(I0{}); else run(I1{});

@@ -14,6 +14,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <exception>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -94,9 +95,13 @@ extern "C" int mi355_plan_arity(const char* name) {
 
 extern "C" void* mi355_plan_create(int n) {
   if (n < 0) return nullptr;
-  Plan* p = new Plan();
-  p->l.resize(n);
-  return p;
+  try {
+    Plan* p = new Plan();
+    p->l.resize(n);
+    return p;
+  } catch (const std::exception&) {                   // no C++ exception crosses the C ABI
+    return nullptr;
+  }
 }
 
 extern "C" int mi355_plan_set(void* plan, int i, const char* name, const uint64_t* args, int nargs, int flags) {
@@ -114,10 +119,16 @@ extern "C" int mi355_plan_set(void* plan, int i, const char* name, const uint64_
     mi355_set_error("plan_set: %s takes %d arguments, got %d", name, e->nargs, nargs);
     return MI355_ERR_ARG;
   }
-  p->l[i].e = e;
-  p->l[i].flags = flags;
-  p->l[i].off = (uint32_t)p->args.size();
-  p->args.insert(p->args.end(), args, args + nargs);
+  try {
+    const uint32_t off = (uint32_t)p->args.size();
+    p->args.insert(p->args.end(), args, args + nargs);
+    p->l[i].e = e;
+    p->l[i].flags = flags;
+    p->l[i].off = off;
+  } catch (const std::exception& ex) {
+    mi355_set_error("plan_set: %s", ex.what());
+    return MI355_ERR_ARG;
+  }
   return MI355_OK;
 }
 
@@ -155,7 +166,15 @@ extern "C" int mi355_plan_run(void* plan, int first, int last, mi355_stream_t ma
     }
     const bool side = side_stream && (l.flags & FLAG_SIDE);
     if (side && !prev_side) {              // fork: the side group may start once everything issued so far on main is done
-      if ((int)p->fork_ev.size() <= fork) p->fork_ev.resize(fork + 1, nullptr);
+      if ((int)p->fork_ev.size() <= fork) {
+        try {
+          p->fork_ev.resize(fork + 1, nullptr);
+        } catch (const std::exception& ex) {
+          mi355_set_error("plan_run: %s", ex.what());
+          p->last_index = i;
+          return MI355_ERR_ARG;
+        }
+      }
       hipEvent_t& ev = p->fork_ev[fork];
       hipError_t e = hipSuccess;
       if (!ev) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);

@@ -15,6 +15,7 @@
 #include <zlib.h>
 
 #include <atomic>
+#include <exception>
 #include <thread>
 #include <vector>
 
@@ -80,6 +81,10 @@ int walk(const uint8_t* f, long long n, PngHead& hd, const uint8_t*& plte, int& 
   if (!have_ihdr || hd.w == 0 || hd.h == 0) {
     mi355_set_error("png: missing IHDR");
     return MI355_ERR_ARG;
+  }
+  if (hd.w > 32768 || hd.h > 32768) {                 // (a corrupt header must not turn into a multi-gigabyte allocation)
+    mi355_set_error("png: %ux%u exceeds the decoder's 32768 x 32768 limit", hd.w, hd.h);
+    return MI355_ERR_UNSUPPORTED;
   }
   const bool depth_ok = (hd.color == 0 && (hd.depth == 1 || hd.depth == 2 || hd.depth == 4 || hd.depth == 8)) ||
                         (hd.color == 3 && (hd.depth == 1 || hd.depth == 2 || hd.depth == 4 || hd.depth == 8)) ||
@@ -234,7 +239,12 @@ extern "C" int mi355_png_decode(const uint8_t* file, long long nbytes, int chann
     mi355_set_error("png_decode: null output");
     return MI355_ERR_ARG;
   }
-  return decode_one(file, nbytes, channels, out, out_bytes, 0, 0);
+  try {
+    return decode_one(file, nbytes, channels, out, out_bytes, 0, 0);
+  } catch (const std::exception& e) {                 // no C++ exception crosses the C ABI
+    mi355_set_error("png_decode: %s", e.what());
+    return MI355_ERR_ARG;
+  }
 }
 
 extern "C" int mi355_png_decode_batch(const uint8_t* const* files, const long long* nbytes, int n, int channels, uint8_t* out,
@@ -250,7 +260,12 @@ extern "C" int mi355_png_decode_batch(const uint8_t* const* files, const long lo
     for (;;) {
       const int i = next.fetch_add(1);
       if (i >= n) return;
-      const int rc = decode_one(files[i], nbytes[i], channels, out + (size_t)i * stride, stride, W, H);
+      int rc;
+      try {
+        rc = decode_one(files[i], nbytes[i], channels, out + (size_t)i * stride, stride, W, H);
+      } catch (const std::exception&) {
+        rc = MI355_ERR_ARG;
+      }
       if (rc) {
         int zero = 0;
         if (first_err.compare_exchange_strong(zero, rc)) err_index = i;
@@ -258,7 +273,11 @@ extern "C" int mi355_png_decode_batch(const uint8_t* const* files, const long lo
     }
   };
   std::vector<std::thread> pool;
-  for (int t = 1; t < threads; ++t) pool.emplace_back(work);
+  try {
+    for (int t = 1; t < threads; ++t) pool.emplace_back(work);
+  } catch (const std::exception&) {
+    // could not start every worker: the ones that run (and this thread) still drain the queue
+  }
   work();
   for (auto& t : pool) t.join();
   if (first_err.load()) {

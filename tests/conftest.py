@@ -19,3 +19,23 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+_CONFIG = None
+
+
+def pytest_sessionstart(session):
+    global _CONFIG
+    _CONFIG = session.config
+
+
+@pytest.hookimpl(trylast=True)
+def pytest_runtest_logreport(report):
+    """Flush the progress output after every test: with stdout on a pipe or a file pytest's dots sit in a block buffer until the
+    run ends, and a GPU box that sees no output for several minutes takes the run for hung."""
+    if report.when == "teardown" and _CONFIG is not None:
+        tr = _CONFIG.pluginmanager.get_plugin("terminalreporter")
+        if tr is not None:
+            tr.flush()
+        sys.stdout.flush()
+        sys.stderr.flush()

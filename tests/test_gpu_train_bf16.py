@@ -1,11 +1,11 @@
-"""-m gpu: the north-star Dice criterion (configs C3 and C4 in their own dtypes).  Train Attention U-Net for 40 optimiser steps on a learnable
+"""-m gpu: the north-star Dice criterion (configs C3 and C4 in their own dtypes).  Train Attention U-Net for 32 optimiser steps on a learnable
 synthetic task (ellipse visible in the image) three ways from identical weights and batches —
 HIP bf16, HIP fp16 (+ loss scaling, helpers.py:285,323-336), HIP fp32, CPU fp32 oracle (reference semantics:
 BCEWithLogits, clip 1.0, AdamW wd 5e-4) —
 and compare the Dice of the binarised predictions (tester.py:114-134) on 32 held-out images.
 Bound: |Dice - Dice_oracle| <= 1e-3 (0..1 scale) for every GPU mode; final losses within 2 %.
 
-R2AttU_Net (R2AttU_Net.py:88-158, config C4: bf16) runs the same protocol for 12 steps.  Its Dice is still climbing there
+R2AttU_Net (R2AttU_Net.py:88-158, config C4: bf16) runs the same protocol for 8 steps.  Its Dice is still climbing there
 (0.987 -> 0.991 between steps 12 and 20) and 108 shared-weight convolutions per forward make the optimisation trajectory
 chaotic: the fp32 HIP run itself is 2.5e-3 from the oracle at step 12 (and within 1e-3 at step 20), i.e. the distance between
 two trajectories measures summation order, not precision.  The 1e-3 criterion is therefore applied where it is a statement
@@ -33,8 +33,8 @@ def _dice(logit, m):
 
 
 @pytest.mark.parametrize("name,steps,dtypes", [
-    ("AttentionUNet", 40, (torch.float32, torch.bfloat16, torch.float16)),          # C3 (bf16) and C5's segmenter (fp16)
-    ("R2AttU_Net", 12, (torch.float32, torch.bfloat16)),                            # C4 (bf16)
+    ("AttentionUNet", 32, (torch.float32, torch.bfloat16, torch.float16)),          # C3 (bf16) and C5's segmenter (fp16)
+    ("R2AttU_Net", 8, (torch.float32, torch.bfloat16)),                            # C4 (bf16)
 ])
 def test_dice_after_training_matches_oracle(name, steps, dtypes):
     from mi355 import nn as mnn, optim as moptim, amp as mamp
@@ -75,7 +75,7 @@ def test_dice_after_training_matches_oracle(name, steps, dtypes):
         o = moptim.AdamW(m.parameters(), lr=lr, weight_decay=5e-4)
         crit = mnn.BCEWithLogitsLoss()
         # the reference's sequence (helpers.py:320-336); the scaler is a no-op unless fp16.  A small growth interval
-        # makes the scale move inside the 40 steps, and the first steps overflow (d loss / d logit = 2^34 / 16384 > 65504)
+        # makes the scale move inside the 32 steps, and the first steps overflow (d loss / d logit = 2^34 / 16384 > 65504)
         scaler = mamp.GradScaler(init_scale=2.0 ** 34, growth_interval=8, enabled=dtype == torch.float16)
         done = it = 0
         while done < steps and it < steps + 24:

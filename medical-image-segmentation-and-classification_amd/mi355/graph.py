@@ -320,7 +320,7 @@ class Builder:
         self.output = None
         self.dout = None
         self.bn_momentum = 0.1
-        self.acts = []                   # ("relu", a) | ("relu_pre", y, scale, shift[, res]) | ("pool", x, y, k, s, p): see Plan.acts
+        self.acts = []                   # ("relu", a) | ("relu_pre", y, scale, shift) | ("relu_v", y) | ("pool", x, y, k, s, p) | ("gmax", x, argmax)
 
     # ---- allocation ---------------------------------------------------------------------------
     def _alloc(self, numel, dtype=None):
@@ -973,6 +973,8 @@ class Builder:
         v = V(self.f32(x.N * x.C), x.N, x.C)
         am = self._alloc(x.N * x.C, torch.int32)
         self.fwd.append(Launch("mi355_global_pool_fwd", x, x.ld, v, am, x.N, x.H * x.W, x.C, 1 if is_max else 0, self.code))
+        if is_max:
+            self.acts.append(("gmax", x, am))
         v.needs_grad = x.needs_grad
 
         def rule():
@@ -1008,6 +1010,8 @@ class Builder:
         y = V(self.f32(v.B * O), v.B, O)
         self.see(lin.weight, lin.bias)
         self.fwd.append(Launch("mi355_linear_fwd", v, lin.weight, lin.bias, y, v.B, v.F, O, 1 if relu else 0))
+        if relu:
+            self.acts.append(("relu_v", y))
         y.needs_grad = v.needs_grad or lin.weight.requires_grad
         if is_output:
             self.output = ("v", y, (v.B, O))

@@ -96,6 +96,20 @@ def _maxpool(x, k, s, p=0):
     return F.max_pool2d(x, k, s, p)
 
 
+def _gmaxpool(x):
+    """AdaptiveMaxPool2d((1, 1)) + flatten (ResNet.py:112,140) with the arg-max as a recorded / replayed kink."""
+    n, c = x.shape[:2]
+    flat = x.flatten(2)
+    if Kinks.mode == "replay":
+        idx = Kinks.pool[Kinks.i_pool]
+        Kinks.i_pool += 1
+        return flat.gather(2, idx.view(n, c, 1)).view(n, c)
+    v, idx = flat.max(2)
+    if Kinks.mode == "record":
+        Kinks.pool.append(idx.detach())
+    return v
+
+
 def _up2(x):
     return F.interpolate(x, scale_factor=2.0, mode="nearest")
 
@@ -237,7 +251,7 @@ def _resnet_local(sd, x, training, block, counts, drop_mask):
         for b in range(n):
             stride = 2 if (li > 1 and b == 0) else 1
             x = block(sd, f"layer{li}.{b}", x, stride, tr)
-    x = F.adaptive_max_pool2d(x, 1).flatten(1)
+    x = _gmaxpool(x)
     return _head(sd, "fc", x, tr, drop_mask)
 
 

@@ -57,6 +57,12 @@ def gpu_kinks(plan):
             y, sc, sh = a[1], a[2], a[3]
             v = torch.addcmul(sh[: y.C].view(1, 1, 1, -1), y.torch_view().float(), sc[: y.C].view(1, 1, 1, -1))
             relu.append((v > 0).permute(0, 3, 1, 2).contiguous().cpu())
+        elif a[0] == "relu_v":                    # ReLU behind a Linear of a classifier head: fp32 [B, F]
+            y = a[1]
+            relu.append((y.buf[: y.B * y.F].view(y.B, y.F) > 0).cpu())
+        elif a[0] == "gmax":                      # AdaptiveMaxPool2d((1, 1)): the kernel's arg-max pixel per (n, c)
+            x, am = a[1], a[2]
+            pool.append(am[: x.N * x.C].view(x.N, x.C).long().cpu())
         elif a[0] == "pool":
             x, k, s, p = a[1], a[3], a[4], a[5]
             xv = x.torch_view().float().permute(0, 3, 1, 2).contiguous().cpu()

@@ -78,7 +78,7 @@ def test_classifier_gradients_match_fp64_oracle_on_the_same_masks(name, kw, bs, 
     relu, pool = gpu_kinks(out._mi355_plan)
     l64, o64, g64 = replayed_oracle(name, sd, x, y, relu, pool, seg=False)
     assert float((out.detach().cpu().double() - o64).abs().max() / o64.abs().max()) < 1e-4
-    assert abs(float(loss.detach()) - l64) < 1e-5 * max(1.0, abs(l64))
+    assert abs(float(loss.detach()) - l64) < 1e-4 * max(1.0, abs(l64))
     gmax = max(float(v.abs().max()) for v in g64.values())
     errs = {}
     for k, p in m.named_parameters():

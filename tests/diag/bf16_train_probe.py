@@ -1,5 +1,5 @@
 import sys, os, time
-R = os.path.join(os.path.dirname(__file__), '..')
+R = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..')
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'medical-image-segmentation-and-classification_amd'))
 import torch
 from oracle import nets, train as otrain

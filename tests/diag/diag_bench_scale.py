@@ -1,7 +1,7 @@
 """GPU diagnostic (not a test): train-mode forward of AttentionUNet 256x256 batch 32 — HIP fp32 and bf16 against the CPU fp32
 oracle on the SAME full batch (train-mode BatchNorm couples the samples, so the oracle must see all 32 images; ~1-2 min)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "medical-image-segmentation-and-classification_amd"), os.path.join(ROOT, "tests")]
 import numpy as np, torch
 import bench

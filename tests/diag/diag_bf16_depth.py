@@ -1,7 +1,7 @@
 """GPU diagnostic (not a test): where does the bf16 train-mode forward of AttentionUNet drift from the fp32 HIP forward?
 Relative L2 difference of every post-ReLU activation (Plan.acts), in forward order.  usage: diag_bf16_depth.py [batch] [size]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "medical-image-segmentation-and-classification_amd"), os.path.join(ROOT, "tests")]
 import torch
 import bench

@@ -1,7 +1,7 @@
 """GPU diagnostic (not a test): per-tensor gradient error of the fp32 HIP path vs the fp64 oracle, next to the CPU fp32 oracle's
-own error, in parameter order.  usage: python scripts/diag_grads.py AttentionUNet 2 32 [out_channels]"""
+own error, in parameter order.  usage: python tests/diag/diag_grads.py AttentionUNet 2 32 [out_channels]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "medical-image-segmentation-and-classification_amd")]
 import torch
 from oracle import nets, train as otrain

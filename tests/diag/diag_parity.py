@@ -1,8 +1,8 @@
 """GPU diagnostic (not a test): where does the fp32 HIP forward of a model deviate from the fp64 oracle?
 Prints logits errors (eval / train) and, per BatchNorm in forward order, the error of the running statistics after ONE
-train-mode forward next to the CPU fp32 oracle's own error.  Usage: python scripts/diag_parity.py R2AttU_Net 2 32"""
+train-mode forward next to the CPU fp32 oracle's own error.  Usage: python tests/diag/diag_parity.py R2AttU_Net 2 32"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "medical-image-segmentation-and-classification_amd")]
 import torch
 from oracle import nets, train as otrain

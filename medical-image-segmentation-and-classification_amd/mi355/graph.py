@@ -2,9 +2,10 @@
 
 A model's forward is described ONCE per (input shape, mode) as a sequence of C-ABI launches
 over preallocated HBM buffers (`Builder`); the matching backward sequence is generated at the
-same time by reverse-mode rules attached to each op.  Executing a step is then a flat loop of
-ctypes calls on one HIP stream — no tracing, no per-op autograd nodes, no allocation, and the
-whole loop is hipGraph-capturable.
+same time by reverse-mode rules attached to each op.  Executing a step is then the replay of two
+tables of pre-resolved launches by csrc/plan.cpp (one mi355_plan_run call per forward / backward;
+MI355_PLAN_C=0: a flat Python loop of ctypes calls) — no tracing, no per-op autograd nodes, no
+allocation, and the whole step is hipGraph-capturable.
 
 Data layout in HBM: activations are NHWC rows of the compute dtype (bf16 or
 fp32); a concatenation is one wide buffer whose producers write their channel slice directly

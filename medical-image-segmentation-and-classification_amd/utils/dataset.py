@@ -62,6 +62,8 @@ def decode_batch(bufs, channels, threads=8, pin=True):
 
 
 class ClassificationDataset:
+    is_seg = False
+
     def __init__(self, root, transform, split="train"):
         self.root, self.transform = root, transform
         self.samples = []
@@ -86,6 +88,8 @@ class ClassificationDataset:
 
 
 class SegmentationDataset:
+    is_seg = True
+
     def __init__(self, root, transform, split="train"):
         self.root, self.transform = root, transform
         self.pairs = []
@@ -111,14 +115,34 @@ class SegmentationDataset:
         return x[0], y[0]
 
 
+class Subset:
+    """Index subset of one of the datasets above (the reference splits with torch.utils.data.Subset, trainer.py:131-151)."""
+
+    def __init__(self, dataset, indices):
+        self.base, self.indices = dataset, [int(i) for i in indices]
+        self.transform, self.is_seg = dataset.transform, dataset.is_seg
+
+    def __len__(self):
+        return len(self.indices)
+
+    def load_batch(self, idxs, threads=8):
+        return self.base.load_batch([self.indices[i] for i in idxs], threads)
+
+    def __getitem__(self, idx):
+        return self.base[self.indices[idx]]
+
+
 class GpuBatchLoader:
     """DataLoader stand-in for the two datasets above: yields device batches; ``len(loader)`` / ``loader.dataset`` as
     helpers.train() uses them (helpers.py:317-342, 365)."""
 
-    def __init__(self, dataset, batch_size, shuffle=False, drop_last=False, seed=0, threads=8, device="cuda"):
-        self.dataset, self.batch_size, self.shuffle, self.drop_last = dataset, int(batch_size), shuffle, drop_last
+    def __init__(self, dataset, batch_size, shuffle=False, drop_last=False, seed=0, threads=8, device="cuda", indices=None):
+        """``indices``: iterate this subset only (torch.utils.data.Subset semantics, trainer.py:131-151); ``loader.dataset`` then
+        has the subset's length, which is what helpers.train() divides the epoch sums by."""
+        self.batch_size, self.shuffle, self.drop_last = int(batch_size), shuffle, drop_last
         self.gen = torch.Generator().manual_seed(seed)
         self.threads, self.device = threads, torch.device(device)
+        self.dataset = dataset if indices is None else Subset(dataset, indices)
 
     def __len__(self):
         n = len(self.dataset)
@@ -130,7 +154,7 @@ class GpuBatchLoader:
         tf = self.dataset.transform
         for b in range(len(self)):
             idxs = order[b * self.batch_size:(b + 1) * self.batch_size]
-            if isinstance(self.dataset, SegmentationDataset):
+            if self.dataset.is_seg:
                 imgs, masks = self.dataset.load_batch(idxs, self.threads)
                 yield tf(imgs.to(self.device, non_blocking=True), masks.to(self.device, non_blocking=True))
             else:

@@ -7,6 +7,10 @@ out of scope); this driver keeps its protocol — classification 
 defaults to synthetic 256x256 batches so that it runs anywhere:
 
     python utils/trainer.py --task seg --model attentionunet --epochs 2 --samples 64
+
+With ``--data-root dataset`` (the reference's DATA_ROOT layout: ``splits/train.csv``, ``<class>/images|masks/<id>.png``) it reads the
+real files instead: two dataset objects per task with the train / val transforms, one 80/20 index split shared by both
+(trainer.py:119-151), PNGs decoded by native threads and transformed on the GPU (utils/dataset.py, utils/gpu_transforms.py).
 """
 import argparse
 import os
@@ -52,6 +56,7 @@ def main():
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--size", type=int, default=IMG_SIZE)
     ap.add_argument("--save-dir", default="weights")
+    ap.add_argument("--data-root", default=None, help="dataset directory in the reference's layout; default: synthetic batches")
     args = ap.parse_args()
     device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
     if device.type != "cuda":
@@ -59,11 +64,25 @@ def main():
     results = {}
     for task in (["cls", "seg"] if args.task == "both" else [args.task]):
         names = [args.model] if args.model else (CLS_MODELS if task == "cls" else SEG_MODELS)
-        full = synthetic_dataset(task, args.samples, args.size)
-        n_train = int(0.8 * len(full))
-        tr, va = random_split(full, [n_train, len(full) - n_train])
         bs = 16 if task == "cls" else 8
-        train_dl, val_dl = make_loader(tr, bs, True), make_loader(va, bs, False)
+        if args.data_root:
+            from utils.dataset import ClassificationDataset, GpuBatchLoader, SegmentationDataset
+            from utils.gpu_transforms import ClsBatchTransform, SegBatchTransform
+            DS, TF = (ClassificationDataset, ClsBatchTransform) if task == "cls" else (SegmentationDataset, SegBatchTransform)
+            ds_tr = DS(args.data_root, TF(args.size, train=True, device=device), "train")
+            ds_va = DS(args.data_root, TF(args.size, train=False, device=device), "train")
+            if len(ds_tr) == 0:
+                print(f"{task} dataset is empty under {args.data_root}. Skipping.")
+                continue
+            n_train = int(0.8 * len(ds_tr))
+            perm = torch.randperm(len(ds_tr)).tolist()            # (unseeded, like the reference's random_split)
+            train_dl = GpuBatchLoader(ds_tr, bs, shuffle=True, device=device, indices=perm[:n_train])
+            val_dl = GpuBatchLoader(ds_va, bs, shuffle=True, device=device, indices=perm[n_train:])
+        else:
+            full = synthetic_dataset(task, args.samples, args.size)
+            n_train = int(0.8 * len(full))
+            tr, va = random_split(full, [n_train, len(full) - n_train])
+            train_dl, val_dl = make_loader(tr, bs, True), make_loader(va, bs, False)
         for name in names:
             print(f"\n{'=' * 20} {task.upper()} :: {name} {'=' * 20}")
             if task == "cls":

@@ -111,3 +111,26 @@ def test_gpu_batch_loader_feeds_train_ready_batches(tmp_path):
     cds = ClassificationDataset(root, ClsBatchTransform(256, train=False, device=DEV), "train")
     got = [(x.shape, lab.tolist()) for x, lab in GpuBatchLoader(cds, batch_size=3, shuffle=True, seed=1, device=DEV)]
     assert sum(len(l) for _, l in got) == 7 and all(s[1:] == (3, 256, 256) for s, _ in got)
+
+
+def test_train_runs_from_png_files_end_to_end(tmp_path, capsys):
+    """The whole input side in the reference's shape (trainer.py:119-160 -> helpers.train): PNG files on disk, two dataset objects
+    with the train / val transforms over one index split, GpuBatchLoader in DataLoader's place, the drop-in train() on top."""
+    pytest.importorskip("PIL.Image")
+    import os
+    from test_dataset_cpu import make_tree
+    from utils.dataset import GpuBatchLoader, SegmentationDataset
+    from utils.gpu_transforms import SegBatchTransform
+    from utils.helpers import get_seg_model, train
+    root = str(tmp_path / "dataset")
+    make_tree(root, n=13)
+    ds_tr = SegmentationDataset(root, SegBatchTransform(64, train=True, device=DEV), "train")
+    ds_va = SegmentationDataset(root, SegBatchTransform(64, train=False, device=DEV), "train")
+    assert len(ds_tr) == 12
+    perm = torch.randperm(12, generator=torch.Generator().manual_seed(0)).tolist()
+    tr = GpuBatchLoader(ds_tr, 4, shuffle=True, device=DEV, indices=perm[:9])
+    va = GpuBatchLoader(ds_va, 4, shuffle=False, device=DEV, indices=perm[9:])
+    assert len(tr.dataset) == 9 and len(tr) == 3 and len(va.dataset) == 3 and len(va) == 1
+    best = train(get_seg_model("attentionunet"), tr, va, torch.device(DEV), 2, 1e-3, "AttentionUNet", str(tmp_path / "w"), seg=True)
+    out = capsys.readouterr().out
+    assert np.isfinite(best) and "Ep2" in out and os.path.exists(tmp_path / "w" / "AttentionUNet_best_loss.pt")

@@ -142,12 +142,12 @@ _SEG_FILES = {"ResNetUnet": "ResNetUnet_best_loss.pt", "AttentionUNet": "Attenti
 def test_all_models(device="cuda", batch_size=16, cls_loader=None, seg_loader=None, cls_weights_dir=None,
                     seg_weights_dir=None):
     """Evaluate every checkpoint found under the weights directories (tester.py:513-735): same model names, file
-    names, skip rules and result dictionary.  The reference builds its test loaders from `dataset/` with
-    Albumentations (:531-555, :569-580, :651-666), which is the data plane, not this path: the loaders are
-    arguments here (`seg_loader` is expected to carry batch_size // 2 like the reference's, :663), and a missing one
-    takes the reference's "dataset not found" branch (:637-639, :729-731).  The CLIP / CLIPSeg entries (hub models,
-    out of scope: SURVEY.md section 8) are reported and skipped.  Checkpoints are the reference's own format: a plain
-    `state_dict` saved by `train` (helpers.py:394-400)."""
+    names, skip rules and result dictionary.  Like the reference (:531-555, :569-580, :651-666) the test loaders are built
+    from ``DATA_ROOT/splits/test.csv`` with the validation transforms — here `utils.dataset` + `GpuBatchLoader` (native PNG
+    decode, transforms on the GPU), batch_size for classification and batch_size // 2 for segmentation (:663); a caller may pass
+    its own loaders instead, and when neither exists the reference's "dataset not found" branch is taken (:637-639, :729-731).
+    The CLIP / CLIPSeg entries (hub models, out of scope: SURVEY.md section 8) are reported and skipped.  Checkpoints are the
+    reference's own format: a plain `state_dict` saved by `train` (helpers.py:394-400)."""
     from utils.helpers import get_class_model, get_seg_model
     if not torch.cuda.is_available():
         raise RuntimeError("test_all_models: the MI355X path needs a GPU (the reference falls back to the CPU, tester.py:524)")
@@ -181,6 +181,23 @@ def test_all_models(device="cuda", batch_size=16, cls_loader=None, seg_loader=No
                 traceback.print_exc()
                 continue
 
+    def default_loader(seg):
+        """test split of DATA_ROOT through the GPU input pipeline, or None (split file / directory absent)"""
+        try:
+            from utils.dataset import ClassificationDataset, GpuBatchLoader, SegmentationDataset
+            from utils.gpu_transforms import ClsBatchTransform, SegBatchTransform
+            if seg:
+                ds = SegmentationDataset(DATA_ROOT, SegBatchTransform(IMG_SIZE, train=False, device=device), split="test")
+                return GpuBatchLoader(ds, max(1, batch_size // 2), shuffle=False, device=device)
+            ds = ClassificationDataset(DATA_ROOT, ClsBatchTransform(IMG_SIZE, train=False, device=device), split="test")
+            return GpuBatchLoader(ds, batch_size, shuffle=False, device=device)
+        except FileNotFoundError:
+            return None
+
+    if cls_loader is None:
+        cls_loader = default_loader(False)
+    if seg_loader is None:
+        seg_loader = default_loader(True)
     if cls_loader is None:
         print(f"\n[WARNING] Classification test dataset not found: no loader given for {DATA_ROOT!r}")
         print("Skipping classification model testing...")

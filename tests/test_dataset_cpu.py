@@ -12,7 +12,7 @@ pytestmark = pytest.mark.skipif(not available(), reason="libmi355conv.so not bui
 Image = pytest.importorskip("PIL.Image")
 
 
-def make_tree(root, n=7, seed=0):
+def make_tree(root, n=7, seed=0, splits=("train",)):
     g = np.random.RandomState(seed)
     rows = []
     for i in range(n):
@@ -28,8 +28,9 @@ def make_tree(root, n=7, seed=0):
         rows.append((f"{cls}-{i}", cls))
     rows.append(("COVID-missing", "COVID"))                 # listed in the CSV, absent on disk: skipped by both
     os.makedirs(os.path.join(root, "splits"), exist_ok=True)
-    with open(os.path.join(root, "splits", "train.csv"), "w") as f:
-        f.write("id,class\n" + "".join(f"{a},{b}\n" for a, b in rows))
+    for sp in splits:
+        with open(os.path.join(root, "splits", f"{sp}.csv"), "w") as f:
+            f.write("id,class\n" + "".join(f"{a},{b}\n" for a, b in rows))
     return rows
 
 

@@ -339,6 +339,20 @@ def test_test_all_models_walks_the_weight_directories(tmp_path, capsys):
     none = tester.test_all_models("cuda", 4, cls_weights_dir=str(cls_dir), seg_weights_dir=str(seg_dir))
     out = capsys.readouterr().out
     assert none == {} and "Classification test dataset not found" in out and "Segmentation test dataset not found" in out
+    # with a dataset directory in the reference's layout the loaders are built from DATA_ROOT/splits/test.csv (tester.py:567-580,
+    # 651-666): classification at batch_size, segmentation at batch_size // 2, PNGs decoded natively, transforms on the GPU
+    pytest.importorskip("PIL.Image")
+    from test_dataset_cpu import make_tree
+    make_tree(str(tmp_path / "dataset"), n=7, splits=("train", "test"))
+    old_root = tester.DATA_ROOT
+    tester.DATA_ROOT = str(tmp_path / "dataset")
+    try:
+        own = tester.test_all_models("cuda", 4, cls_weights_dir=str(cls_dir), seg_weights_dir=str(seg_dir))
+    finally:
+        tester.DATA_ROOT = old_root
+    out = capsys.readouterr().out
+    assert set(own) == {"ResNet18", "AttentionUNet"} and "Classification Test Dataset: 7 samples" in out
+    assert "Segmentation Test Dataset: 6 samples" in out and own["ResNet18"]["confusion_matrix"].sum() == 7
     tester.print_summary(res)
     tester.save_results_to_csv(res, str(tmp_path / "c.csv"), str(tmp_path / "s.csv"))
     assert (tmp_path / "c.csv").read_text().startswith("Model,accuracy,precision,recall,f1\nResNet18,")

@@ -278,3 +278,17 @@ def save_results_to_csv(results, cls_output_path="results/classification_test_re
         print(f"[INFO] Segmentation results saved to: {seg_output_path}")
     else:
         print("\n[INFO] No segmentation results to save.")
+
+
+if __name__ == "__main__":          # python utils/tester.py (tester.py:879-898): same banner, same three calls
+    import sys
+    PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if PKG not in sys.path:
+        sys.path.insert(0, PKG)
+    print("\n" + "=" * 80)
+    print(" " * 20 + "MODEL TESTING UTILITY")
+    print("=" * 80)
+    results = test_all_models(device="cuda", batch_size=16)
+    print_summary(results)
+    save_results_to_csv(results, cls_output_path="classification_test_results.csv", seg_output_path="segmentation_test_results.csv")
+    print("\n[INFO] Testing complete!")

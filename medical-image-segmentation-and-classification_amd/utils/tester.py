@@ -4,10 +4,16 @@ loops :197-312).  Per-sample counters come from one HIP reduction per batch inst
 syncs per sample."""
 import os
 
+import sys
+
 import numpy as np
 import torch
 
-from mi355.lib import lib
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))       # `python utils/tester.py` (tester.py:22-24 does the same)
+if _PKG not in sys.path:
+    sys.path.insert(0, _PKG)
+
+from mi355.lib import lib  # noqa: E402
 
 CLASSES = ["COVID", "Healthy", "Non-COVID"]
 DATA_ROOT = "dataset"
@@ -281,10 +287,6 @@ def save_results_to_csv(results, cls_output_path="results/classification_test_re
 
 
 if __name__ == "__main__":          # python utils/tester.py (tester.py:879-898): same banner, same three calls
-    import sys
-    PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    if PKG not in sys.path:
-        sys.path.insert(0, PKG)
     print("\n" + "=" * 80)
     print(" " * 20 + "MODEL TESTING UTILITY")
     print("=" * 80)

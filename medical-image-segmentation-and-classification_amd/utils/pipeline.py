@@ -58,6 +58,16 @@ class JointPipeline:
             segmented = torch.zeros_like(segmented)
         return {"pred": pred, "confidence": conf, "masks": masks, "segmented": segmented}
 
+    def process_files(self, paths, size=256, threads=8):
+        """PNG files -> the reference's per-image results.  The reference opens each file with PIL, applies ``A.Resize(256, 256)`` +
+        ``A.Normalize`` + ``ToTensorV2`` (pipeline.py:186-193, 381-390) and runs the two models; here the files of one size are
+        decoded by native threads (utils/dataset.py) and resized / normalised on the GPU (utils/gpu_transforms.py) as ONE batch."""
+        from utils.dataset import decode_batch, read_files
+        from utils.gpu_transforms import SegBatchTransform
+        imgs = decode_batch(read_files(paths), 3, threads)
+        x = SegBatchTransform(size, train=False, device=self.device)(imgs.to(self.device, non_blocking=True))
+        return self.process_batch(x)
+
     def process_batch(self, x):
         """The reference's per-image result shape: list of (prediction, confidence_percent, mask uint8 [H,W] or None)."""
         r = self.predict(x)

@@ -149,3 +149,32 @@ def test_pipeline_glue_kernels():
     exp[4] = (torch.sigmoid(lg[0, 0]) > 0.5).to(torch.uint8) * 255
     exp[1] = (torch.sigmoid(lg[1, 0]) > 0.5).to(torch.uint8) * 255
     assert torch.equal(out.cpu(), exp)
+
+
+def test_pipeline_from_png_files(tmp_path):
+    """JointPipeline.process_files: PNG files -> native decode -> A.Resize(256) + Normalize on the GPU -> classify -> segment the
+    "COVID" ones; equal to process_batch on the oracle's per-sample transform of the PIL-decoded images (pipeline.py:381-398)."""
+    Image = pytest.importorskip("PIL.Image")
+    import numpy as np
+    from oracle import transforms as ot
+    from utils.pipeline import JointPipeline
+    cls_sd, seg_sd, _, _ = _fixture("ResNet18")
+    cm, sm = _models(torch.float32, cls_sd, seg_sd, "ResNet18")
+    g = np.random.RandomState(2)
+    paths = []
+    for i in range(5):
+        yy, xx = np.mgrid[0:299, 0:299]
+        img = (127 + 80 * np.sin(xx / (9.0 + i)) * np.cos(yy / (6.0 + i)) + g.randint(-10, 10, (299, 299))).clip(0, 255).astype(np.uint8)
+        p = str(tmp_path / f"x{i}.png")
+        Image.fromarray(img, "L").save(p)
+        paths.append(p)
+    pipe = JointPipeline(cm, sm, device=DEV, bucket=4)
+    got = pipe.process_files(paths, size=64)
+    xs = torch.stack([torch.from_numpy(ot.normalize_u8(ot.warp_u8(np.array(Image.open(p).convert("RGB")), ot.resize_matrix(299, 299, 64, 64), 64, 64)))
+                      for p in paths])
+    want = pipe.process_batch(xs)
+    assert [g_[0] for g_ in got] == [w[0] for w in want]
+    for (p1, c1, m1), (p2, c2, m2) in zip(got, want):
+        assert abs(c1 - c2) <= 1e-2 * c2 and (m1 is None) == (m2 is None)
+        if m1 is not None:
+            assert float((m1 != m2).float().mean()) <= 5e-3

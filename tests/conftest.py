@@ -24,9 +24,27 @@ def golden_dir():
 _CONFIG = None
 
 
+def _usable_cores():
+    """the affinity mask capped by the cgroup CPU quota (a 1-GPU box shows every core of its host but owns a 16-core share)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def pytest_sessionstart(session):
     global _CONFIG
     _CONFIG = session.config
+    # the oracle is CPU torch: its default thread count is the host's core count, which oversubscribes a quota'd box many times over
+    import torch
+    torch.set_num_threads(min(_usable_cores(), 16))
 
 
 @pytest.hookimpl(trylast=True)

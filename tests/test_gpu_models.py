@@ -82,36 +82,17 @@ def test_fp32_model_matches_reference_golden_and_oracle(name):
     assert _rel(out.detach().cpu().numpy(), z["logits_train"]) < 1e-4      # measured 1.4e-5 (R2AttU_Net) .. 5e-5 (AttentionUNet) vs fp64
     assert abs(float(loss.detach()) - float(z["loss"])) < RTOL * max(1.0, abs(float(z["loss"])))
 
-    # Gradients.  These fixtures (batch 2, 2x2..4x4 deepest level, up to 100+ stacked train-mode BNs)
-    # are chaotic in fp32: torch-CPU fp32 itself sits 1e-2 (median over parameters; 1e-1 for the
-    # recurrent nets) away from an fp64 evaluation and moves 1e-3 with its thread count.  Parity is
-    # therefore stated against fp64 truth: the HIP fp32 path must be as close to it as the reference's
-    # own fp32 CPU path is (median within 3x, worst tensor within 5x, floor 1e-3).  Sharp element-wise
-    # bounds live in test_gpu_blocks.py (1e-4 vs the reference blocks) and in the well-conditioned
-    # ResNet18 case below.
+    # Gradients against the REFERENCE's values.  Both sides are fp32 evaluations of a discontinuous function (DESIGN.md section 5:
+    # a dozen ReLU masks differ between any two evaluations and move every gradient by ~1e-3..1e-2), so the golden gradient
+    # norms are matched to 8 % here; the sharp statement — every gradient tensor to rounding accuracy against the fp64 oracle
+    # on the GPU's own masks — is tests/test_gpu_kinks.py, on these same fixtures.
     names = [str(s) for s in z["param_names"]]
     params = dict(m.named_parameters())
     assert names == list(params.keys())
-    _, _, g32 = otrain.forward_backward(name, {k: v.clone() for k, v in sd.items()}, x, y, seg)
-    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
-    _, o64, g64 = otrain.forward_backward(name, sd64, x.double(), y.double() if seg else y, seg)
-    e_out_cpu = _rel(z["logits_train"], o64.numpy())
-    assert _rel(out.detach().cpu().numpy(), o64.numpy()) < max(RTOL, 4 * e_out_cpu)
-    gmax = max(float(v.abs().max()) for v in g64.values())
-    e_gpu, e_cpu = [], []
-    for k in names:
-        ref = g64[k].numpy()
-        scale = np.abs(ref).max()
-        if scale < 1e-6 * gmax:
-            continue                                   # mathematically-zero gradients (bias in front of a BN)
-        e_gpu.append(np.abs(params[k].grad.cpu().numpy() - ref).max() / scale)
-        e_cpu.append(np.abs(g32[k].numpy() - ref).max() / scale)
-    med_g, med_c, max_g, max_c = np.median(e_gpu), np.median(e_cpu), np.max(e_gpu), np.max(e_cpu)
-    assert med_g <= max(RTOL, 3 * med_c), (med_g, med_c)
-    assert max_g <= max(RTOL, 5 * max_c), (max_g, max_c)
     gn = np.array([float(params[k].grad.double().norm()) for k in names])
     big = z["grad_norm"] > 1e-5 * z["grad_norm"].max()
-    assert np.allclose(gn[big], z["grad_norm"][big], rtol=max(5e-3, 15 * med_c)), np.abs(gn[big] / z["grad_norm"][big] - 1).max()
+    dev = np.abs(gn[big] / z["grad_norm"][big] - 1)
+    assert np.median(dev) <= 1e-2 and dev.max() <= 8e-2, (np.median(dev), dev.max())
     # BN buffers after one train-mode forward
     msd = m.state_dict()
     for k, l2 in zip([str(s) for s in z["buffer_names"]], z["buffer_l2_after"]):
@@ -124,7 +105,7 @@ def test_fp32_model_matches_reference_golden_and_oracle(name):
     total = moptim.clip_grad_norm_(m.parameters(), 1.0)
     opt.step()
     torch.cuda.synchronize()
-    assert abs(float(total) - float(z["total_grad_norm"])) < max(5e-3, 15 * med_c) * float(z["total_grad_norm"])
+    assert abs(float(total) - float(z["total_grad_norm"])) < 3e-2 * float(z["total_grad_norm"])
     numel = np.array([params[k].numel() for k in names])
     l2 = np.array([float(params[k].detach().double().norm()) for k in names])
     assert np.all(np.abs(l2 - z["param_l2_after"]) <= 1e-5 * l2 + 0.3 * lr * np.sqrt(numel))
@@ -222,8 +203,8 @@ def test_state_dict_roundtrip_and_no_cpu_fallback():
 def test_resnet_unet_matches_oracle_fp32():
     """ResNetUnet (config 2).  The reference class needs torchvision (absent), so this model is checked
     against the oracle only (parity unpinned at the torchvision-encoder boundary): logits,
-    loss, frozen-encoder semantics, BN buffers and — anchored on fp64 like the other nets — the decoder
-    gradients, including both ConvTranspose2d backward paths."""
+    loss, frozen-encoder semantics, BN buffers and — against the fp64 oracle on the GPU's own ReLU / max-pool decisions — the
+    decoder gradients, including both ConvTranspose2d backward paths."""
     from mi355 import nn as mnn
     from models.segmentation_models.ResnetUnet import ResNetUnet
     name = "ResNetUnet"
@@ -247,35 +228,38 @@ def test_resnet_unet_matches_oracle_fp32():
     assert frozen and all(k.startswith("encoder") for k in frozen)
     assert all(p.grad is None for k, p in m.named_parameters() if k in frozen)
 
-    def oracle(dtype):
-        s = {k: (v.to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
-        pk = [k for k in nets.param_keys(s) if k not in frozen]
-        for k in pk:
-            s[k].requires_grad_(True)
-        o = nets.resnet_unet(s, x.to(dtype), True)
-        l = otrain.bce_with_logits(o, mask.to(dtype))
-        l.backward()
-        return o.detach(), float(l), {k: s[k].grad for k in pk}, s
-
-    o64, l64, g64, _ = oracle(torch.float64)
-    o32, l32, g32, s32 = oracle(torch.float32)
-    assert _rel(out.detach().cpu().numpy(), o64.numpy()) < max(RTOL, 4 * _rel(o32.numpy(), o64.numpy()))
-    assert abs(float(loss.detach()) - l64) < RTOL
+    # the fp64 oracle on the GPU's own ReLU / max-pool decisions (tests/test_gpu_kinks.py): the two evaluate the same smooth function
+    from gpu_util import gpu_kinks
+    relu, pool = gpu_kinks(out._mi355_plan)
+    s64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    pk = [k for k in nets.param_keys(s64) if k not in frozen]
+    for k in pk:
+        s64[k].requires_grad_(True)
+    nets.Kinks.start("replay", relu, pool)
+    try:
+        o64 = nets.resnet_unet(s64, x.double(), True)
+        l64 = otrain.bce_with_logits(o64, mask.double())
+        l64.backward()
+    finally:
+        _, _, used = nets.Kinks.stop()
+    assert used == (len(relu), len(pool)) and len(pool) == 1, used
+    assert _rel(out.detach().cpu().numpy(), o64.detach().numpy()) < 5e-4          # ~110 fp32 layers (measured 1.4e-4)
+    assert abs(float(loss.detach()) - float(l64.detach())) < 2e-5
     params = dict(m.named_parameters())
-    gmax = max(float(v.abs().max()) for v in g64.values())
-    e_gpu, e_cpu = [], []
-    for k, ref in g64.items():
+    gmax = max(float(s64[k].grad.abs().max()) for k in pk)
+    errs = {}
+    for k in pk:
+        ref = s64[k].grad
         sc = float(ref.abs().max())
-        if sc < 1e-6 * gmax:
-            continue
-        e_gpu.append(float((params[k].grad.cpu().double() - ref).abs().max()) / sc)
-        e_cpu.append(float((g32[k].double() - ref).abs().max()) / sc)
-    assert np.median(e_gpu) <= max(RTOL, 3 * np.median(e_cpu)), (np.median(e_gpu), np.median(e_cpu))
-    assert np.max(e_gpu) <= max(RTOL, 5 * np.max(e_cpu)), (np.max(e_gpu), np.max(e_cpu))
+        if sc >= 1e-6 * gmax:
+            errs[k] = float((params[k].grad.cpu().double() - ref).abs().max()) / sc
+    e = np.array(list(errs.values()))
+    # (the decoder sees the frozen ResNet50 encoder's fp32 activations, 1.4e-4 off fp64 at the logits: measured median 6e-5, max 5e-4)
+    assert np.median(e) <= 2e-4 and e.max() <= 2e-3, (np.median(e), max(errs, key=errs.get), e.max())
     msd = m.state_dict()
-    for k, v in s32.items():
+    for k, v in s64.items():
         if k.endswith(("running_mean", "running_var")):
-            assert _rel(msd[k].cpu().numpy(), v.detach().numpy()) < RTOL, k
+            assert _rel(msd[k].cpu().numpy(), v.detach().numpy()) < 1e-4, k
 
 
 def test_tester_functions_match_oracle_metrics(capsys):
@@ -441,34 +425,15 @@ def test_recurrent_weight_gradients_one_launch_matches_per_application(monkeypat
         assert float((g - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-12, k
 
 
-def _pool_gap(sd64, x, cfg):
-    """smallest relative gap between the two largest values of a 2x2 max-pool window (positive maximum) anywhere in
-    the VGG16_BN feature stack, evaluated in fp64"""
-    import torch.nn.functional as F
-    idx, gap, t = 0, 1.0, x.double()
-    for c in cfg:
-        if c == "M":
-            n, ch, h, w = t.shape
-            s = t.reshape(n, ch, h // 2, 2, w // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, ch, h // 2, w // 2, 4).sort(-1, descending=True).values
-            gap = min(gap, float(((s[..., 0] - s[..., 1]) / s[..., 0].clamp_min(1e-30))[s[..., 0] > 0].min()))
-            t = F.max_pool2d(t, 2, 2)
-            idx += 1
-        else:
-            t = F.relu(nets._bn(dict(sd64), f"features.{idx + 1}", nets._conv(sd64, f"features.{idx}", t, 1, 1), True))
-            idx += 3
-    return gap
-
-
 @pytest.mark.parametrize("name", ["VGG16_BN", "VGG19_BN"])
 def test_vgg_bn_matches_oracle_fp32(name):
     """torchvision-layout vgg16_bn / vgg19_bn (the models helpers.py:158-166 requests from the hub; vgg16_bn is config 5's classifier).
     torchvision is absent, so the check is against the oracle only (parity unpinned at this boundary): eval and
-    train logits, loss, gradients anchored on fp64 like the other nets, BN buffers.  64x64 input -> 2x2 feature
+    train logits, loss and every gradient tensor against the fp64 oracle on the GPU's own kink decisions.  64x64 input -> 2x2 feature
     map, so AdaptiveAvgPool2d((7,7)) runs its up-sampling branch (overlapping / repeated windows)."""
     from mi355 import nn as mnn
     from models.classification_models import VGG
     from utils.helpers import add_dropout_to_fc
-    cfg = nets.VGG16_CFG if name == "VGG16_BN" else nets.VGG19_CFG
     sd = nets.closed_form_state(name, num_classes=3, head_dropout=True)
     m = getattr(VGG, name)(num_classes=1000)
     assert add_dropout_to_fc(m, p=0.0) == "classifier"
@@ -478,16 +443,7 @@ def test_vgg_bn_matches_oracle_fp32(name):
     m.load_state_dict(sd)
     m.compute_dtype = torch.float32
     m = m.to(DEV)
-    # 260 k max-pool windows: the closest runner-up sits ~1e-7 (relative) below the maximum, and ANY fp32 evaluation
-    # may route that window's gradient to the other element — a valid subgradient, but an O(1e-2) max-norm
-    # difference to fp64 (observed: exactly one flipped window).  Pick, among shifted copies of the closed-form
-    # input, the one whose tightest window is widest, so that the fixture tests arithmetic and not tie-breaking.
-    x0, _ = otrain.closed_form_input(2, 64)
-    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
-    cands = [x0.roll((i, j), dims=(2, 3)) for i in range(4) for j in range(4)]
-    gaps = [_pool_gap(sd64, c, cfg) for c in cands]
-    x = cands[int(np.argmax(gaps))]
-    assert max(gaps) > 2e-6, gaps
+    x, _ = otrain.closed_form_input(2, 64)
     y = torch.tensor([1, 2])
     m.eval()
     with torch.no_grad():
@@ -499,21 +455,23 @@ def test_vgg_bn_matches_oracle_fp32(name):
     loss = mnn.CrossEntropyLoss(label_smoothing=0.1)(out, y.to(DEV))
     loss.backward()
     torch.cuda.synchronize()
-    l32, o32, g32 = otrain.forward_backward(name, {k: v.clone() for k, v in sd.items()}, x, y, False)
-    l64, o64, g64 = otrain.forward_backward(name, sd64, x.double(), y, False)
-    assert _rel(out.detach().cpu().numpy(), o64.numpy()) < max(RTOL, 4 * _rel(o32.numpy(), o64.numpy()))
-    assert abs(float(loss.detach()) - l64) < RTOL * max(1.0, abs(l64))
+    # 260 k max-pool windows, the tightest ~1e-7 (relative) wide: any fp32 evaluation may route such a window's gradient to the
+    # runner-up.  The fp64 oracle therefore replays the GPU's ReLU masks and pool arg-maxes (tests/test_gpu_kinks.py).
+    from gpu_util import gpu_kinks, replayed_oracle
+    relu, pool = gpu_kinks(out._mi355_plan)
+    l64, o64, g64 = replayed_oracle(name, sd, x, y, relu, pool, seg=False)
+    assert len(pool) == 5
+    assert _rel(out.detach().cpu().numpy(), o64.numpy()) < 1e-4
+    assert abs(float(loss.detach()) - l64) < 1e-5 * max(1.0, abs(l64))
     params = dict(m.named_parameters())
     gmax = max(float(v.abs().max()) for v in g64.values())
-    e_gpu, e_cpu = [], []
+    errs = {}
     for k, ref in g64.items():
         sc = float(ref.abs().max())
-        if sc < 1e-6 * gmax:
-            continue
-        e_gpu.append(float((params[k].grad.cpu().double() - ref).abs().max()) / sc)
-        e_cpu.append(float((g32[k].double() - ref).abs().max()) / sc)
-    assert np.median(e_gpu) <= max(RTOL, 3 * np.median(e_cpu)), (np.median(e_gpu), np.median(e_cpu))
-    assert np.max(e_gpu) <= max(RTOL, 5 * np.max(e_cpu)), (np.max(e_gpu), np.max(e_cpu))
+        if sc >= 1e-6 * gmax:
+            errs[k] = float((params[k].grad.cpu().double() - ref).abs().max()) / sc
+    e = np.array(list(errs.values()))
+    assert np.median(e) <= 5e-5 and e.max() <= 1e-3, (np.median(e), max(errs, key=errs.get), e.max())
 
 
 @pytest.mark.parametrize("name,ctor_kw,spec_kw,cin", [
@@ -591,22 +549,20 @@ def test_torchvision_layout_resnets_match_oracle_fp32(name):
     loss = mnn.CrossEntropyLoss(label_smoothing=0.1)(out, y.to(DEV))
     loss.backward()
     torch.cuda.synchronize()
-    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
-    l64, o64, g64 = otrain.forward_backward(name, sd64, x.double(), y, False)
-    _, o32, g32 = otrain.forward_backward(name, {k: v.clone() for k, v in sd.items()}, x, y, False)
+    from gpu_util import gpu_kinks, replayed_oracle
+    relu, pool = gpu_kinks(out._mi355_plan)
+    l64, o64, g64 = replayed_oracle(name, sd, x, y, relu, pool, seg=False)
     assert _rel(out.detach().cpu().numpy(), o64.numpy()) < 1e-4
     assert abs(float(loss.detach()) - l64) < 1e-4 * max(1.0, abs(l64))
     params = dict(m.named_parameters())
     gmax = max(float(v.abs().max()) for v in g64.values())
-    e_gpu, e_cpu = [], []
+    errs = {}
     for k, ref in g64.items():
         sc = float(ref.abs().max())
-        if sc < 1e-6 * gmax:
-            continue
-        e_gpu.append(float((params[k].grad.cpu().double() - ref).abs().max()) / sc)
-        e_cpu.append(float((g32[k].double() - ref).abs().max()) / sc)
-    assert np.median(e_gpu) <= max(1e-4, 3 * np.median(e_cpu)), (np.median(e_gpu), np.median(e_cpu))
-    assert np.max(e_gpu) <= max(RTOL, 5 * np.max(e_cpu)), (np.max(e_gpu), np.max(e_cpu))
+        if sc >= 1e-6 * gmax:
+            errs[k] = float((params[k].grad.cpu().double() - ref).abs().max()) / sc
+    e = np.array(list(errs.values()))
+    assert np.median(e) <= 2e-4 and e.max() <= 2e-3, (np.median(e), max(errs, key=errs.get), e.max())
     msd = m.state_dict()
     _, _, _ = otrain.forward_backward(name, sd, x, y, False)          # (updates the oracle's BN buffers in place)
     for k, v in sd.items():

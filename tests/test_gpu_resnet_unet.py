@@ -76,7 +76,8 @@ def test_frozen_encoder_clip_and_adamw_match_oracle():
         want_all.append((0.1 * coef * raw[k]).reshape(-1).double())
         # AdamW's first step moves every element by lr * sign(g) (+ decay): parameters agree far inside lr, except where a
         # rounding-level gradient has the other sign (2 lr apart)
-        assert float(((params[k].detach().cpu() - s[k]).abs() <= 0.5 * lr).float().mean()) >= 0.98, k
+        off = int(((params[k].detach().cpu() - s[k]).abs() > 0.5 * lr).sum())
+        assert off <= max(2, 0.02 * s[k].numel()), (k, off, s[k].numel())
     got_all, want_all = torch.cat(got_all), torch.cat(want_all)
     # first moments = (1 - beta1) * coef * g: the projection onto the oracle's clipped gradient is 1 when the clip coefficient
     # was applied (1 / coef = 1.24 when it was dropped).  Element-wise this 2x64x64 fixture is ill-conditioned in fp32

@@ -87,6 +87,27 @@ template <> __device__ __forceinline__ f32x4 mfma_16x16x32<f16_t>(bf16x8 a, bf16
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
+// In-place forms (inline asm, accumulator tied to the destination).  The builtin lets the register allocator give D a tuple
+// different from C (the early-clobber 3-address form): accumulators then wander through the file and every MFMA needs a spare
+// tuple — fine with registers to spare, 200+ spills in a kernel that keeps 128 accumulators in a 256-register budget.
+// The compiler inserts the operand waits (lgkmcnt of the fragment reads) but NOT the MFMA -> VALU read wait states of its hazard
+// recogniser: a kernel using these calls mfma_results_ready() before any non-MFMA instruction reads an accumulator.
+template <typename T> __device__ __forceinline__ void mfma_16x16x32_acc(bf16x8 a, bf16x8 b, f32x4& c);
+template <> __device__ __forceinline__ void mfma_16x16x32_acc<bf16_t>(bf16x8 a, bf16x8 b, f32x4& c) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+template <> __device__ __forceinline__ void mfma_16x16x32_acc<f16_t>(bf16x8 a, bf16x8 b, f32x4& c) {
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+template <typename T> __device__ __forceinline__ void mfma_16x16x32_first(bf16x8 a, bf16x8 b, f32x4& c);      // c = a * b
+template <> __device__ __forceinline__ void mfma_16x16x32_first<bf16_t>(bf16x8 a, bf16x8 b, f32x4& c) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
+}
+template <> __device__ __forceinline__ void mfma_16x16x32_first<f16_t>(bf16x8 a, bf16x8 b, f32x4& c) {
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_results_ready() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), result in every lane: quad_perm [1,0,3,2], [2,3,0,1], then

@@ -506,6 +506,7 @@ static int launch_dma(const ConvArgs& a, hipStream_t s) {
 
 #include "conv3x3_halo.hpp"
 #include "conv3x3_halo_pp.hpp"
+#include "conv3x3_halo_pp128.hpp"
 #include "conv1x1_stream.hpp"
 
 template <typename T, int BN, int BK>
@@ -523,7 +524,7 @@ static int launch_bn(const ConvArgs& a, hipStream_t s) {
   return launch<T, 32, BK>(a, s);
 }
 
-enum IgemmVariant { IG_GENERIC = 0, IG_DMA, IG_HALO_8x32, IG_HALO_16x16, IG_STREAM1x1, IG_HALO_PP };
+enum IgemmVariant { IG_GENERIC = 0, IG_DMA, IG_HALO_8x32, IG_HALO_16x16, IG_STREAM1x1, IG_HALO_PP, IG_HALO_PP128 };
 
 // ONE place that decides which kernel serves a shape (also used by the statistics-row query).
 static IgemmVariant pick_variant(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int mul, int kmul, int off,
@@ -541,6 +542,13 @@ static IgemmVariant pick_variant(int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
     // exposes every tile's prologue and epilogue) -> the 4-wave kernel below stays the default; the variant is kept selectable.
     static const int use_pp = getenv("MI355_HALO_PP") ? atoi(getenv("MI355_HALO_PP")) : 0;
     if (use_pp && Wo % 32 == 0 && Ho % 16 == 0) return IG_HALO_PP;
+    // 16 x 32 pixels x 128 channels, ping-pong halves (conv3x3_halo_pp128.hpp): half the operand bytes per FLOP; one workgroup
+    // per CU, so only where the reduction is deep enough to amortise a tile's prologue and epilogue.  Measured per layer
+    // (profiles/r02b_conv_layers_*): Ci >= 512 +10-14 %, Ci = 256 +4-7 %, Ci = 128 -2..+2 % -> threshold 256.
+    // MI355_HALO_PP128=0 switches it off (A/B), MI355_HALO_PP128_MINCI moves the threshold.
+    static const int pp128 = getenv("MI355_HALO_PP128") ? atoi(getenv("MI355_HALO_PP128")) : 1;
+    static const int pp128_min_ci = getenv("MI355_HALO_PP128_MINCI") ? atoi(getenv("MI355_HALO_PP128_MINCI")) : 256;
+    if (pp128 && Co % 128 == 0 && Ci % 64 == 0 && Ci >= pp128_min_ci && Wo % 32 == 0 && Ho % 16 == 0) return IG_HALO_PP128;
     if (Wo % 32 == 0 && Ho % 8 == 0) return IG_HALO_8x32;
     if (Wo % 16 == 0 && Ho % 16 == 0) return IG_HALO_16x16;
   }
@@ -559,7 +567,8 @@ extern "C" int mi355_conv2d_igemm_variant(int Hi, int Wi, int Ci, int Ho, int Wo
 extern "C" int mi355_conv2d_igemm_stat_rows(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int mul,
                                             int kmul, int off, int div, int up, int dtype) {
   switch (pick_variant(Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up, dtype)) {
-    case IG_HALO_PP: return N * (Ho / 16) * (Wo / 32);
+    case IG_HALO_PP:
+    case IG_HALO_PP128: return N * (Ho / 16) * (Wo / 32);
     case IG_HALO_8x32: return N * (Ho / 8) * (Wo / 32);
     case IG_HALO_16x16: return N * (Ho / 16) * (Wo / 16);
     case IG_DMA: return ceil_div((long long)N * Ho * Wo, 128);
@@ -597,7 +606,7 @@ extern "C" int mi355_conv2d_igemm(const void* in, const void* wk, const float* b
   a.accumulate = accumulate & 1;
   a.relu = (accumulate >> 1) & 1;
   a.pool2 = (accumulate >> 2) & 1;
-  MI355_CHECK_ARG(!a.pool2 || ((v == IG_HALO_8x32 || v == IG_HALO_16x16 || v == IG_HALO_PP) && !stats),
+  MI355_CHECK_ARG(!a.pool2 || ((v == IG_HALO_8x32 || v == IG_HALO_16x16 || v == IG_HALO_PP || v == IG_HALO_PP128) && !stats),
                   "conv2d_igemm: the 2x2-sum epilogue exists for the halo kernel only (mi355_conv2d_igemm_variant >= 2)");
   a.stats = stats;
   a.M = N * Ho * Wo;
@@ -612,6 +621,7 @@ extern "C" int mi355_conv2d_igemm(const void* in, const void* wk, const float* b
     if constexpr (sizeof(T) == 2) {
       switch (v) {
         case IG_HALO_PP: return launch_halo_pp<T>(a, st);
+        case IG_HALO_PP128: return launch_halo_pp128<T>(a, st);
         case IG_HALO_8x32: return launch_halo_rw<T, 8, 32>(a, st);
         case IG_HALO_16x16: return launch_halo_rw<T, 16, 16>(a, st);
         case IG_STREAM1x1: return launch_stream1x1<T>(a, st);

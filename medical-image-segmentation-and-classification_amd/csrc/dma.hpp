@@ -32,6 +32,20 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_base) {
       : "v"(gsrc), "s"(lds_base)
       : "memory");
 }
+// The same piece with a wave-uniform base (an SGPR pair) and a 32-bit per-lane byte offset: one VGPR per source instead of a
+// 64-bit address pair — what the 512-thread kernels, which have no registers to spare, keep per piece.
+__device__ __forceinline__ void dma16_sv(const void* sbase, unsigned voff, unsigned lds_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_base)
+      : "memory");
+}
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) void*)p);
 }

@@ -530,7 +530,7 @@ class Builder:
                     acc = self.acc_flag(x)
                     xg = self.grad_of(x)
                     tag = self.igemm_tag(x.C, Co, k, s, 2 * x.H, 2 * x.W, True, False, M=x.N * 4 * x.H * x.W)
-                    if lib.mi355_conv2d_igemm_variant(Ho, Wo, Co, 2 * x.H, 2 * x.W, x.C, k, k, 1, -1, p, s, 0, self.code) in (2, 3, 5):
+                    if lib.mi355_conv2d_igemm_variant(Ho, Wo, Co, 2 * x.H, 2 * x.W, x.C, k, k, 1, -1, p, s, 0, self.code) in (2, 3, 5, 6):
                         # the data gradient lives on the up-sampled grid; its 2x2 sums go straight to the half-resolution
                         # gradient in the kernel epilogue (no full-resolution temporary, no separate pass)
                         self.bwd.append(Launch("mi355_conv2d_igemm", dy, wb, None, xg, x.N, Ho, Wo, Co, dy.ld, 2 * x.H, 2 * x.W,
@@ -573,6 +573,9 @@ class Builder:
         if k == 3 and s == 1 and co % 64 == 0 and not (dgrad and up):
             if Wo % 32 == 0 and Ho % 16 == 0 and os.environ.get("MI355_HALO_PP", "0") == "1":
                 return "conv3x3_halo_pp_kernel"
+            if (Wo % 32 == 0 and Ho % 16 == 0 and co % 128 == 0 and ci % 64 == 0 and os.environ.get("MI355_HALO_PP128", "1") != "0"
+                    and ci >= int(os.environ.get("MI355_HALO_PP128_MINCI", "256"))):
+                return "conv3x3_halo_pp128_kernel"
             if Wo % 32 == 0 and Ho % 8 == 0:
                 return "conv3x3_halo_rw_kernel<8,32>"
             if Wo % 16 == 0 and Ho % 16 == 0:

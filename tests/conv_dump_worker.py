@@ -15,6 +15,8 @@ from gpu_util import DEV, DTYPE_CODE, lib, pack_w, to_nhwc
 CASES = [  # N, Ci, H, W, Co, k, up          (halo 8x32 / 16x16 / ping-pong-eligible / igemm-DMA 1x1 and strided shapes)
     (2, 64, 16, 32, 128, 3, 0), (1, 160, 32, 64, 64, 3, 0), (2, 96, 16, 16, 192, 3, 0), (2, 64, 8, 16, 128, 3, 1),
     (3, 256, 9, 7, 128, 1, 0), (4, 128, 24, 32, 64, 3, 0),
+    # 128-channel ping-pong kernel at its default threshold (Ci >= 256): forward only / forward and data gradient / fused up-sampling
+    (2, 256, 32, 64, 128, 3, 0), (2, 256, 16, 32, 256, 3, 0), (1, 256, 8, 16, 128, 3, 1),
 ]
 
 

@@ -36,6 +36,12 @@ CASES = [  # N, Ci, H, W, Co, K, stride, pad, up
     (3, 64, 16, 96, 192, 3, 1, 1, 0),
     (2, 64, 16, 32, 64, 3, 1, 1, 1),
     (1, 256, 16, 32, 64, 3, 1, 1, 0),
+    # 128-channel ping-pong kernel (conv3x3_halo_pp128.hpp: Co % 128 == 0, Ci % 64 == 0): two / four / six slabs, one and several
+    # tiles per image, two channel tiles, fused up-sampling; the data gradients of these cases run it with Ci and Co swapped
+    (2, 128, 32, 64, 256, 3, 1, 1, 0),
+    (1, 192, 16, 32, 128, 3, 1, 1, 0),
+    (2, 64, 8, 16, 128, 3, 1, 1, 1),
+    (1, 128, 48, 32, 128, 3, 1, 1, 0),
 ]
 
 
@@ -223,6 +229,7 @@ def test_conv_wgrad(case, dtype):
 
 
 @pytest.mark.parametrize("case", [(2, 64, 16, 32, 128, 3, 1, 1, 0), (2, 96, 32, 64, 64, 3, 1, 1, 0), (2, 96, 16, 16, 64, 3, 1, 1, 0), (3, 64, 9, 7, 64, 1, 1, 0, 0),
+                                  (2, 128, 32, 64, 256, 3, 1, 1, 0),
                                   (2, 64, 8, 16, 128, 3, 1, 1, 1), (1, 32, 5, 5, 128, 3, 2, 1, 0)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_conv_fused_bn_statistics(case, dtype):
@@ -310,6 +317,29 @@ def test_ping_pong_halo_variant_passes_the_same_cases():
     assert r.returncode == 0, r.stdout[-3000:]
     code = DTYPE_CODE[torch.bfloat16]
     assert lib.mi355_conv2d_igemm_variant(32, 64, 64, 32, 64, 64, 3, 3, 1, 1, -1, 1, 0, code) == 2          # default: the 4-wave kernel
+
+
+def test_128_channel_ping_pong_variant_passes_the_same_cases():
+    """conv3x3_halo_pp128.hpp (16 x 32 pixels x 128 channels per 512-thread workgroup; the default from Ci = 256 up) with the
+    threshold lowered to every eligible shape (MI355_HALO_PP128_MINCI=64) in a child process: forward / data gradient / statistics /
+    2x2-sum cases; and the default dispatch: it serves 256-deep reductions, the 4-wave kernel the shallow ones."""
+    import os, subprocess, sys
+    if os.environ.get("MI355_HALO_PP128_MINCI"):
+        pytest.skip("already the child process")
+    env = dict(os.environ, MI355_HALO_PP128="1", MI355_HALO_PP128_MINCI="64")
+    here = os.path.dirname(os.path.abspath(__file__))
+    pkg = os.path.join(os.path.dirname(here), "medical-image-segmentation-and-classification_amd")
+    probe = ("import sys; sys.path[:0] = [%r, %r]; from gpu_util import lib, DTYPE_CODE; import torch; "
+             "print(lib.mi355_conv2d_igemm_variant(32, 64, 128, 32, 64, 256, 3, 3, 1, 1, -1, 1, 0, DTYPE_CODE[torch.bfloat16]))" % (here, pkg))
+    r = subprocess.run([sys.executable, "-c", probe], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("6"), (r.stdout, r.stderr[-2000:])       # IG_HALO_PP128
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
+                        "fwd or dgrad or statistics or upsampled"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    code = DTYPE_CODE[torch.bfloat16]
+    assert lib.mi355_conv2d_igemm_variant(32, 64, 256, 32, 64, 128, 3, 3, 1, 1, -1, 1, 0, code) == 6
+    assert lib.mi355_conv2d_igemm_variant(32, 64, 128, 32, 64, 128, 3, 3, 1, 1, -1, 1, 0, code) == 2
+    assert lib.mi355_conv2d_igemm_variant(32, 64, 256, 32, 64, 64, 3, 3, 1, 1, -1, 1, 0, code) == 2
 
 
 def test_counted_vmcnt_matches_drained_build(tmp_path):

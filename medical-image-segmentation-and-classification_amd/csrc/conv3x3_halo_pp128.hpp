@@ -24,8 +24,11 @@
 
 struct HaloPp128Cfg {
   static constexpr int TH = 16, TW = 32, HTH = 8, BN = 128;
-  static constexpr int NPIX = (TH + 2) * (TW + 2);
-  static constexpr int P_INSTR = (NPIX + 15) / 16;
+  static constexpr int PWL = 36;                                         // patch row pitch in LDS (pixels): a multiple of four, so that
+                                                                         // the swizzle bit of a pixel is (row + (x >> 2)) & 1 — see the
+                                                                         // fragment addresses in the kernel; columns 34, 35 are never read
+  static constexpr int NPIX = (TH + 2) * PWL;
+  static constexpr int P_INSTR = (NPIX + 15) / 16;                       // 41 DMA instructions of 16 pixels per slab
   static constexpr int PATCH_BYTES = P_INSTR * 1024;
   static constexpr int STAGE_BYTES = 3 * BN * 64;
   static constexpr int NS = 3;
@@ -42,10 +45,11 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pp128_kernel(const ConvArgs 
   typedef HaloPp128Cfg Cfg;
   constexpr int TH = Cfg::TH, TW = Cfg::TW, HTH = Cfg::HTH;
   constexpr int BN = Cfg::BN, BK = 32, EPC = 8, HBM = HTH * TW;            // 256 pixels per half
-  constexpr int PW = TW + 2, NPIX = Cfg::NPIX;
+  constexpr int PW = TW + 2, PWL = Cfg::PWL, NPIX = Cfg::NPIX;
   constexpr int PIXB = BK * 2;
   constexpr int P_INSTR = Cfg::P_INSTR;
-  constexpr int P_IT = (P_INSTR + 7) / 8;            // patch pieces per wave (8 waves)
+  constexpr int P_IT = P_INSTR / 8;                  // patch pieces every wave brings (pieces w, w + 8, ...); piece 40 is wave 0's sixth
+  static_assert(P_INSTR == 8 * P_IT + 1, "one left-over piece");
   constexpr int PATCH_BYTES = Cfg::PATCH_BYTES;
   constexpr int SLAB = BN * PIXB, STAGE = Cfg::STAGE_BYTES;
   constexpr int WN = 2, WTM = HBM / 2, WTN = BN / WN;
@@ -79,16 +83,17 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pp128_kernel(const ConvArgs 
   // per-lane source of every patch piece as a 32-bit BYTE offset inside image n (0xffffffff: padding -> zero page); the image
   // base and the piece's LDS destination are wave-uniform (scalar registers)
   const char* const img = reinterpret_cast<const char*>(in + (size_t)n * a.Hi * a.Wi * a.ldi);
-  unsigned p_off[P_IT];
+  unsigned p_off[P_IT + 1];                          // ([P_IT]: the left-over piece, used by wave 0 only)
 #pragma unroll
-  for (int i = 0; i < P_IT; ++i) {
-    const int piece = min(wave + 8 * i, P_INSTR - 1);
+  for (int i = 0; i <= P_IT; ++i) {
+    const int piece = i < P_IT ? wave + 8 * i : P_INSTR - 1;
     const int q = piece * 16 + lrow;
-    const int py = q / PW, px = q - py * PW;
+    const int py = q / PWL, px = q - py * PWL;
     const int yy = y0 - 1 + py, xx = x0 - 1 + px;
-    const bool ok = q < NPIX && (unsigned)yy < (unsigned)a.Hlog && (unsigned)xx < (unsigned)a.Wlog;
+    const bool ok = q < NPIX && px < PW && (unsigned)yy < (unsigned)a.Hlog && (unsigned)xx < (unsigned)a.Wlog;
     p_off[i] = ok ? (unsigned)((((yy >> a.up) * a.Wi + (xx >> a.up)) * a.ldi + (slot ^ (((q >> 2) & 1) << 1)) * EPC) * 2) : 0xffffffffu;
   }
+  const unsigned lds0 = lds_addr(lds);               // LDS byte address of the ring (DMA destinations are integers)
   unsigned char* const patch0 = lds;
   unsigned char* const bring = lds + Cfg::NPB * PATCH_BYTES;
   // padding lanes take no part in the DMA (EXEC off): their 16-byte slots of both patch buffers are zeroed ONCE, below — a
@@ -96,14 +101,16 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pp128_kernel(const ConvArgs 
   // 32-bit offset: no 64-bit address is ever formed in vector registers.
   auto issue_patch_piece = [&](int buf, int c0, int i) __attribute__((always_inline)) {
     const unsigned o = p_off[i];
-    if (o != 0xffffffffu) dma16_sv(img + c0 * 2, o, lds_addr(patch0 + buf * PATCH_BYTES + min(wave + 8 * i, P_INSTR - 1) * 1024));
+    const int piece = i < P_IT ? wave + 8 * i : P_INSTR - 1;
+    if (o != 0xffffffffu) dma16_sv_m0(img + c0 * 2, o, lds0 + buf * PATCH_BYTES + piece * 1024);
   };
 #pragma unroll
-  for (int i = 0; i < P_IT; ++i)
-    if (p_off[i] == 0xffffffffu) {
+  for (int i = 0; i <= P_IT; ++i)
+    if (p_off[i] == 0xffffffffu && (i < P_IT || wave == 0)) {
+      const int piece = i < P_IT ? wave + 8 * i : P_INSTR - 1;
 #pragma unroll
       for (int b = 0; b < Cfg::NPB; ++b)
-        *reinterpret_cast<uint4*>(patch0 + b * PATCH_BYTES + min(wave + 8 * i, P_INSTR - 1) * 1024 + lane * 16) = uint4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<uint4*>(patch0 + b * PATCH_BYTES + piece * 1024 + lane * 16) = uint4{0u, 0u, 0u, 0u};
     }
   // weight stage = the three taps (ph = 0, 1, 2) of patch column pw, 8 KiB each = eight 1-KiB pieces of 16 rows: wave w brings
   // rows [16 w, +16) of all three slabs.
@@ -111,10 +118,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pp128_kernel(const ConvArgs 
   const int brow = wave * 16 + lrow;
   const T* const wk0 = wk + (size_t)n0 * wrow;                                            // wave-uniform
   const unsigned b_off = (unsigned)(((size_t)brow * wrow + (slot ^ (((brow >> 2) & 1) << 1)) * EPC) * 2);
-  auto issue_stage_piece = [&](int stage, int pw, int c0, int ph) __attribute__((always_inline)) {      // c0 < 0: nothing left to fetch (zeros into a dead slot)
+  auto issue_stage_piece = [&](int stage, int pw, int c0, int ph) __attribute__((always_inline)) {
     const int tap = flip ? (2 - ph) * 3 + (2 - pw) : ph * 3 + pw;
-    const char* sb = c0 >= 0 ? reinterpret_cast<const char*>(wk0 + (size_t)tap * a.Ci + c0) : zero;
-    dma16_sv(sb, c0 >= 0 ? b_off : (unsigned)slot * 16u, lds_addr(bring + stage * STAGE + wave * 1024 + ph * SLAB));
+    dma16_sv_m0(wk0 + (size_t)tap * a.Ci + c0, b_off, lds0 + Cfg::NPB * PATCH_BYTES + stage * STAGE + wave * 1024 + ph * SLAB);
   };
   auto issue_stage = [&](int stage, int pw, int c0) __attribute__((always_inline)) {
 #pragma unroll
@@ -124,11 +130,18 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pp128_kernel(const ConvArgs 
   const int nC = a.Ci / BK;
 
   // ---- fragment geometry -----------------------------------------------------------------------------------------------
-  const int q00 = (half * HTH) * PW + wm * 16 + l16;
+  // Pixel fragment of (patch row pr, column shift pw): pixel q = (8 half + pr) * 36 + x, x = 16 wm + l16 + pw.  With a pitch
+  // that is a multiple of four the swizzle bit (q >> 2) & 1 is (pr + (x >> 2)) & 1: the ten row addresses of a column shift are
+  // ONE lane register (even rows; odd rows: the same XOR 32) plus the immediate pr * 2304 — three registers and one XOR per load
+  // phase instead of six VALU operations per row (the 34-pixel pitch of the other halo kernels needs those).
+  int a_even[3];
+#pragma unroll
+  for (int pw = 0; pw < 3; ++pw) {
+    const int x = wm * 16 + l16 + pw;
+    a_even[pw] = (half * HTH * PWL + x) * PIXB + ((c4 ^ (((x >> 2) & 1) << 1)) << 4);
+  }
   const int brow0 = wn * WTN + l16;
   const int boff0 = brow0 * PIXB + ((c4 ^ (((brow0 >> 2) & 1) << 1)) << 4);
-  // (the 4-wave kernel keeps the 18 fragment offsets [patch column][patch row] in registers; here the R phase has VALU slots to
-  // spare and the registers do not: the offsets are rebuilt from q00 — five VALU operations per patch row and phase)
   // (the first MFMA of a block takes a literal zero as its C operand; the bias joins in the epilogue — 16 registers the main
   // loop does not have to carry)
   f32x4 acc[MB][NB];
@@ -152,6 +165,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pp128_kernel(const ConvArgs 
   using Yes = std::true_type;
 #pragma unroll
   for (int i = 0; i < P_IT; ++i) issue_patch_piece(0, 0, i);
+  if (wave == 0) issue_patch_piece(0, 0, P_IT);
   issue_stage(0, 0, 0);
   issue_stage(1, 1, 0);
   wait_vmcnt<3>();                                                                // all but stage 1
@@ -180,20 +194,14 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pp128_kernel(const ConvArgs 
         bfr[ph][nb] = *reinterpret_cast<const bf16x8*>(pb_ + ph * SLAB + (h * NBH + nb) * 16 * PIXB + boff0);
     if constexpr (h == 0) {
       const unsigned char* pa = patch0 + pb * PATCH_BYTES;
-      int qb = q00;
-      asm volatile("" : "+v"(qb));                     // (opaque: the offsets must not be hoisted into loop-invariant registers)
+      int ae = a_even[pw];
+      asm volatile("" : "+v"(ae));                     // (opaque: one base register per parity, the rows are immediates)
+      int ao = ae ^ 32;
+      asm volatile("" : "+v"(ao));
 #pragma unroll
-      for (int pr = 0; pr < NPR; ++pr) {
-#ifdef PP128_T_FLATADDR      // timing only: one address computation for all ten rows (wrong fragments, same reads)
-        const int q = qb + pw;
-        const int ao = q * PIXB + ((c4 ^ (((q >> 2) & 1) << 1)) << 4) + pr * PW * PIXB;
-#else
-        const int q = qb + pr * PW + pw;
-        const int ao = q * PIXB + ((c4 ^ (((q >> 2) & 1) << 1)) << 4);
-#endif
-#pragma unroll
-        for (int xb = 0; xb < XB; ++xb) afr[pr][xb] = *reinterpret_cast<const bf16x8*>(pa + xb * 16 * PIXB + ao);
-      }
+      for (int pr = 0; pr < NPR; ++pr)
+        afr[pr][0] = *reinterpret_cast<const bf16x8*>(pa + ((pr & 1) ? ao : ae) + pr * PWL * PIXB);
+      static_assert(XB == 1, "one 16-pixel block per wave row");
       __builtin_amdgcn_sched_barrier(0);
       // this sub-step's share of the patch of slab chunk + 1 (buffer pb ^ 1: last read during slab chunk - 1)
       constexpr int i0 = pw == 0 ? 0 : (pw == 1 ? PA[0] + PB[0] : PA[0] + PB[0] + PA[1] + PB[1]), i1 = i0 + PA[pw];
@@ -203,13 +211,18 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pp128_kernel(const ConvArgs 
         issue_patch_piece(pb ^ 1, cp, i);
 #endif
       }
+      // wave 0's left-over piece travels with the slab's last regular one: in front of this step's stage, so that the pw == 2 wait
+      // (everything but that stage) covers it and no other count changes
+      if constexpr (pw == 2) {
+        if (wave == 0) issue_patch_piece(pb ^ 1, cp, P_IT);
+      }
     } else {
       __builtin_amdgcn_sched_barrier(0);
       // the stage two steps ahead (ring slot of step s - 1, last read in half 1's R(s - 1, 1), several phases ago)
       constexpr int pw2 = (pw + 2) % 3;
       const int c2 = (pw == 0 ? chunk : chunk + 1);
 #ifndef PP128_T_NODMA        // timing only: no DMA inside the loop (stale operands)
-      issue_stage(pw2, pw2, c2 < nC ? c2 * BK : -1);
+      issue_stage(pw2, pw2, min(c2, nC - 1) * BK);       // (past the last step: the last slab again, into a dead slot)
       constexpr int i0 = (pw == 0 ? 0 : (pw == 1 ? PA[0] + PB[0] : PA[0] + PB[0] + PA[1] + PB[1])) + PA[pw], i1 = i0 + PB[pw];
 #pragma unroll
       for (int i = i0; i < i1; ++i) issue_patch_piece(pb ^ 1, cp, i);

@@ -559,6 +559,21 @@ static IgemmVariant pick_variant(int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
   return IG_DMA;
 }
 
+// The 128-channel ping-pong kernel runs ONE 512-thread workgroup per CU: a grid that leaves a quarter of the last round of
+// workgroups empty (or does not fill the chip once: 32 images of 32 x 32 x 256 channels = 128 workgroups) is served by the
+// 4-wave kernel, whose grid is four times finer.  Batch-dependent, hence not part of the shape-level variant query.
+static IgemmVariant resolve_variant(IgemmVariant v, int N, int Ho, int Wo, int Co) {
+  if (v != IG_HALO_PP128) return v;
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+  }();
+  const long long grid = (long long)N * (Ho / 16) * (Wo / 32) * (Co / 128);
+  const long long rounds = (grid + cus - 1) / cus;
+  return grid * 5 >= rounds * cus * 4 ? IG_HALO_PP128 : IG_HALO_8x32;          // >= 80 % of the last round filled
+}
+
 extern "C" int mi355_conv2d_igemm_variant(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int mul, int kmul, int off,
                                           int div, int up, int dtype) {
   return (int)pick_variant(Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up, dtype);
@@ -566,7 +581,7 @@ extern "C" int mi355_conv2d_igemm_variant(int Hi, int Wi, int Ci, int Ho, int Wo
 
 extern "C" int mi355_conv2d_igemm_stat_rows(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int mul,
                                             int kmul, int off, int div, int up, int dtype) {
-  switch (pick_variant(Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up, dtype)) {
+  switch (resolve_variant(pick_variant(Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up, dtype), N, Ho, Wo, Co)) {
     case IG_HALO_PP:
     case IG_HALO_PP128: return N * (Ho / 16) * (Wo / 32);
     case IG_HALO_8x32: return N * (Ho / 8) * (Wo / 32);
@@ -593,7 +608,7 @@ extern "C" int mi355_conv2d_igemm(const void* in, const void* wk, const float* b
                       (ldi * esz) % 16 == 0 && (ldo * esz) % 16 == 0,
                   "conv2d_igemm: pointers / channel strides must be 16-byte aligned");
   MI355_CHECK_ARG(Ci % (esz == 2 ? 32 : 16) == 0, "conv2d_igemm: Ci=%d must be a multiple of %d", Ci, esz == 2 ? 32 : 16);
-  const IgemmVariant v = pick_variant(Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up, dtype);
+  const IgemmVariant v = resolve_variant(pick_variant(Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up, dtype), N, Ho, Wo, Co);
   MI355_CHECK_ARG(!stats || (v != IG_GENERIC && !(accumulate & 1)),
                   "conv2d_igemm: fused statistics are not available for this shape/dtype (mi355_conv2d_igemm_stat_rows == 0)");
   ConvArgs a;

@@ -60,7 +60,9 @@ def _worker(rank, world, port, q):
             opt.step()
         torch.cuda.synchronize()
         plan = [p for p in m.engine.plans.values() if p.dout is not None][0]
-        q.put((rank, "ok", m.engine.flat_p.detach().cpu(), len(dp.schedule(plan))))
+        # a numpy array travels through the queue by value; a torch tensor travels as a file descriptor that the parent must fetch
+        # from this process while it is still alive (seen once: ConnectionResetError when the worker had already exited)
+        q.put((rank, "ok", m.engine.flat_p.detach().cpu().numpy(), len(dp.schedule(plan))))
     except Exception:  # noqa: BLE001
         import traceback
         q.put((rank, "fail", traceback.format_exc(), 0))
@@ -80,7 +82,7 @@ def test_dp_world2_matches_single_process_emulation():
         p.join(timeout=60)
     for rank, status, info, _ in res:
         assert status == "ok", f"rank {rank}: {info}"
-    p0, p1 = res[0][2], res[1][2]
+    p0, p1 = torch.from_numpy(res[0][2]), torch.from_numpy(res[1][2])
     assert res[0][3] > 1                              # 140 MB of gradients in 8 MB buckets: the overlap path ran
     assert torch.equal(p0, p1)                        # same reduced gradients + same update => bit-identical replicas
 

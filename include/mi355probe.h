@@ -9,6 +9,10 @@ extern "C" {
  * registers; mode 1: plus 18 ds_read_b128 fragment reads per trip, the halo kernel's LDS diet) or 24 v_mfma_f32_32x32x16_bf16
  * (mode 2).  rnd: 1 MiB of finite bf16 bit patterns; s: hipStream_t. */
 int mi355_probe_mfma(int mode, const void* rnd, int blocks, int iters, float* sink, void* s);
+/* One 1-KiB LDS-DMA piece through a buffer descriptor (dma.hpp: dma16_buf): lane i fetches 16 B at src + soff + 16 i, lanes in
+ * `pad_mask` use the always-out-of-range offset, valid == 0 sets num_records = 0.  out[256]: the KiB found in LDS afterwards
+ * (pre-filled with 0x7f bytes) — tests/test_gpu_conv.py pins that the range check writes zeros. */
+int mi355_probe_bufdma(const void* src, unsigned soff, unsigned long long pad_mask, int valid, unsigned* out, void* s);
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,34 @@ __device__ __forceinline__ void dma16_sv_m0(const void* sbase, unsigned voff, un
       : "memory", "m0");
 }
 #pragma clang diagnostic pop
+// LDS-DMA through a buffer descriptor: source = descriptor base + scalar offset `soff` + the lane's 32-bit byte offset, and the
+// hardware's range check does the padding — a lane whose offset is >= the descriptor's num_records reads ZEROS (0x80000000 with
+// the num_records below; the scalar offset takes no part in the check), and a descriptor with num_records = 0 zero-fills the
+// whole piece.  No zero page, no per-lane address select, no EXEC masking, and every wave issues the same number of pieces
+// whatever its lanes' validity (the counted vmcnt waits rely on that).  M0 clobbered as above.
+typedef int __attribute__((ext_vector_type(4))) bufdesc_t;
+constexpr unsigned DMA_PAD = 0x80000000u;            // a lane offset that is always out of range
+__device__ __forceinline__ bufdesc_t make_buf(const void* base, bool valid = true) {
+  const unsigned long long p = (unsigned long long)base;
+  bufdesc_t d;
+  d[0] = (int)(unsigned)p;
+  d[1] = (int)(unsigned)((p >> 32) & 0xffffu);       // stride 0: a raw buffer
+  d[2] = valid ? (int)DMA_PAD : 0;                    // num_records (bytes): every real offset is < 2^31
+  d[3] = 0x00020000;                                  // DATA_FORMAT = 32 (untyped dword loads ignore the format fields)
+  return d;
+}
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void dma16_buf(bufdesc_t desc, unsigned voff, unsigned soff, unsigned lds_byte) {
+  asm volatile(
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %0, %1, %2 offen lds"
+      :
+      : "v"(voff), "s"(desc), "s"(soff), "s"(lds_byte)
+      : "memory", "m0");
+}
+#pragma clang diagnostic pop
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) void*)p);
 }

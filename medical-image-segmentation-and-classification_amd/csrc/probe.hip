@@ -73,3 +73,24 @@ extern "C" int mi355_probe_mfma(int mode, const void* rnd, int blocks, int iters
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }
+
+
+// ---- LDS-DMA through a buffer descriptor: what the range check writes ------------------------------------------------------
+// 64 lanes fetch 16 B each from `src` (+ soff bytes); lanes with bit k of `pad_mask` set use the always-out-of-range offset;
+// valid == 0 gives the descriptor num_records = 0.  out[256] = the 1 KiB that arrived in LDS (pre-filled with 0x7f bytes).
+#include "dma.hpp"
+__global__ void probe_bufdma_kernel(const void* src, unsigned soff, unsigned long long pad_mask, int valid, unsigned* out) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[1024];
+  const int lane = threadIdx.x;
+  reinterpret_cast<uint4*>(lds)[lane] = make_uint4(0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu);
+  __syncthreads();
+  const bufdesc_t d = make_buf(src, valid != 0);
+  dma16_buf(d, ((pad_mask >> lane) & 1) ? DMA_PAD : lane * 16u, __builtin_amdgcn_readfirstlane(soff), lds_addr(lds));
+  wait_vmcnt<0>();
+  __syncthreads();
+  for (int i = lane; i < 256; i += 64) out[i] = reinterpret_cast<unsigned*>(lds)[i];
+}
+extern "C" int mi355_probe_bufdma(const void* src, unsigned soff, unsigned long long pad_mask, int valid, unsigned* out, mi355_stream_t s) {
+  hipLaunchKernelGGL(probe_bufdma_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, src, soff, pad_mask, valid, out);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}

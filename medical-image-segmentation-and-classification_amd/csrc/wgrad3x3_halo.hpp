@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args 
   unsigned char* const xr = lds;
   unsigned char* const dr = lds + X_BYTES;
   unsigned char* const dump = lds + ZERO_IMG;
+  const unsigned lds_x = lds_addr(xr), lds_d = lds_addr(dr), lds_dump = lds_addr(dump);      // DMA destinations: LDS byte addresses
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l16 = lane & 15, c4 = lane >> 4;
@@ -125,19 +126,34 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args 
       xpix[k] = half * a.Hi * a.Wi + (xx >> a.up);
     }
 
-    auto issue_row = [&](int r, int xs, int ds) {   // xs / ds: ring slots of X row r / dY row r
-      {
-        const bool ok = lane_ok_d && r >= ya && r < yb;
-        const char* p = ok ? reinterpret_cast<const char*>(dy + ((size_t)(nbase * a.H + r) * a.W + dpix) * a.ldy + c_d) : zero + slot * 16;
-        dma16(p, lds_addr(dr + ds * DROW + wave * 1024));
-      }
+    // DMA sources: a buffer descriptor per tensor whose base is image `nbase` (wave-uniform), a scalar row offset, and ONE
+    // 32-bit register per piece holding the lane's offset inside the row — or the always-out-of-range offset where the lane is
+    // padding (image column / channel range), so that the hardware's range check writes the zeros; a row outside the image
+    // (X) or the band (dY) takes a descriptor with num_records = 0.  Nothing per-lane is computed or selected per row.
+    const bufdesc_t desc_d = make_buf(dy + (size_t)nbase * a.H * a.W * a.ldy);
+    const bufdesc_t desc_x = make_buf(x + (size_t)nbase * a.Hi * a.Wi * a.ldx);
+    const unsigned voff_d = lane_ok_d ? (unsigned)((dpix * a.ldy + c_d) * (int)sizeof(T)) : DMA_PAD;
+    unsigned voff_x[2];
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const bool ok = lane_ok_x[k] && (unsigned)r < (unsigned)a.H;
-        const char* p = ok ? reinterpret_cast<const char*>(x + ((size_t)(nbase * a.Hi + (r >> a.up)) * a.Wi + xpix[k]) * a.ldx + c_x[k])
-                           : zero + slot * 16;
-        dma16(p, lds_addr(real_x[k] ? xr + xs * XROW + xpiece[k] * 1024 : dump + wave * 1024));
+    for (int k = 0; k < 2; ++k) voff_x[k] = lane_ok_x[k] ? (unsigned)((xpix[k] * a.ldx + c_x[k]) * (int)sizeof(T)) : DMA_PAD;
+    const unsigned d_stride = (unsigned)(a.W * a.ldy) * (unsigned)sizeof(T), x_stride = (unsigned)(a.Wi * a.ldx) * (unsigned)sizeof(T);
+    auto with_rows = [](bufdesc_t d, bool ok) { d[2] = ok ? (int)DMA_PAD : 0; return d; };
+    // piece 0: this wave's KiB of dY row r; pieces 1, 2: its KiB(s) of X row r.  xs / ds: ring slots of X row r / dY row r
+    auto issue_piece = [&](int piece, int r, unsigned d_soff, unsigned x_soff, int xs, int ds) {
+      if (piece == 0) {
+        dma16_buf(with_rows(desc_d, r >= ya && r < yb), voff_d, d_soff, lds_d + ds * DROW + wave * 1024);
+      } else {
+        const int k = piece - 1;
+        dma16_buf(with_rows(desc_x, (unsigned)r < (unsigned)a.H), voff_x[k], x_soff,
+                  real_x[k] ? lds_x + xs * XROW + xpiece[k] * 1024 : lds_dump + wave * 1024);
       }
+    };
+    auto issue_at = [&](int r, unsigned d_soff, unsigned x_soff, int xs, int ds) {
+#pragma unroll
+      for (int piece = 0; piece < 3; ++piece) issue_piece(piece, r, d_soff, x_soff, xs, ds);
+    };
+    auto issue_row = [&](int r, int xs, int ds) {
+      issue_at(r, (unsigned)r * d_stride, (unsigned)(r >> a.up) * x_stride, xs, ds);      // (r = -1: a dead offset under num_records = 0)
     };
     // X fragments of tap column kw: [ci block]; dY fragments of a row: [co block]
     auto load_x = [&](int xs, int kw, bf16x8 (&bf)[2]) {
@@ -149,43 +165,34 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args 
       for (int ao = 0; ao < 2; ++ao) af[ao] = frag(off, pl, colA + 16 * ao);
     };
     bf16x8 dp[2], dc[2], dm[2], dn[2];              // dY rows r+1, r, r-1 (kh = 0, 1, 2) and the incoming r+2
-    auto mfma12 = [&](int kw, const bf16x8 (&xk)[2]) {
+    // twelve MFMAs of tap column kw; `between(kh)` runs behind the four MFMAs of tap row kh (a DMA piece rides there: in the
+    // matrix pipe's shadow, one at a time — three back to back stall the pipe for their issue time)
+    auto mfma12 = [&](int kw, const bf16x8 (&xk)[2], auto between) {
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
+      for (int kh = 0; kh < 3; ++kh) {
 #pragma unroll
         for (int ao = 0; ao < 2; ++ao)
 #pragma unroll
           for (int bi = 0; bi < 2; ++bi)
-            acc[kh * 3 + kw][ao][bi] = mfma_16x16x32<T>(kh == 0 ? dp[ao] : (kh == 1 ? dc[ao] : dm[ao]), xk[bi], acc[kh * 3 + kw][ao][bi]);
+            mfma_16x16x32_acc<T>(kh == 0 ? dp[ao] : (kh == 1 ? dc[ao] : dm[ao]), xk[bi], acc[kh * 3 + kw][ao][bi]);
+        between(kh);
+      }
     };
     auto wrap = [](int v, int n) { return v >= n ? v - n : v; };
     // The rows the main loop fetches are CONSECUTIVE (ya + 2, ya + 3, ...): their per-lane source pointers advance by a row
     // stride instead of being rebuilt from (n, r, x) with 64-bit multiplies each time, and the lane part of the bounds test
     // (channel / image-column range) is taken once per item; only the row part, wave-uniform, is evaluated per row.
-    const int off_d = (dpix * a.ldy + c_d) * (int)sizeof(T);                  // per-lane byte offset from the row base (32 bit)
-    const char* drow_next = reinterpret_cast<const char*>(dy + (size_t)(nbase * a.H + ya + 2) * a.W * a.ldy);      // wave-uniform
-    const size_t d_stride = (size_t)a.W * a.ldy * sizeof(T);
-    int off_x[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) off_x[k] = (xpix[k] * a.ldx + c_x[k]) * (int)sizeof(T);
-    const char* xrow_next = reinterpret_cast<const char*>(x + (size_t)(nbase * a.Hi + ((ya + 2) >> a.up)) * a.Wi * a.ldx);
-    const size_t x_stride = (size_t)a.Wi * a.ldx * sizeof(T);
+    unsigned d_soff_next = (unsigned)(ya + 2) * d_stride, x_soff_next = (unsigned)((ya + 2) >> a.up) * x_stride;      // scalar registers
     int r_next = ya + 2;
-    auto issue_next = [&](int xs, int ds) {          // row r_next into ring slots xs / ds, then advance
-      {
-        const bool ok = lane_ok_d && r_next >= ya && r_next < yb;
-        const char* p = ok ? drow_next + off_d : zero + slot * 16;
-        dma16(p, lds_addr(dr + ds * DROW + wave * 1024));
+    auto issue_next_piece = [&](int piece, int xs, int ds) {      // row r_next into ring slots xs / ds; the last piece advances
+#ifndef WG3_T_NODMA                                            // (timing-only build: stale rows, the no-DMA ceiling of the loop)
+      issue_piece(piece, r_next, d_soff_next, x_soff_next, xs, ds);
+#endif
+      if (piece == 2) {
+        d_soff_next += d_stride;
+        if (!a.up || (r_next & 1)) x_soff_next += x_stride;  // the source row of an up-sampled input advances every second row
+        ++r_next;
       }
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const bool ok = lane_ok_x[k] && (unsigned)r_next < (unsigned)a.H;
-        const char* p = ok ? xrow_next + off_x[k] : zero + slot * 16;
-        dma16(p, lds_addr(real_x[k] ? xr + xs * XROW + xpiece[k] * 1024 : dump + wave * 1024));
-      }
-      drow_next += d_stride;
-      if (!a.up || (r_next & 1)) xrow_next += x_stride;      // the source row of an up-sampled input advances every second row
-      ++r_next;
     };
 
     // ring slots: X row q -> (q - (ya-1)) mod NRX, dY row q -> (q - (ya-1)) mod NRD
@@ -204,17 +211,17 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args 
     // constant (four step bodies per trip), so every LDS offset of the step is an instruction immediate.
     auto row_step = [&](int r, auto slot_tag, bf16x8 (&xa)[2], bf16x8 (&xb)[2]) {
       constexpr int S = decltype(slot_tag)::value;
-      load_x(S, 1, xb);
-      mfma12(0, xa);
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);      // the next tap column's fragments first, then this one's MFMAs
-      __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-      // row r+3 is fetched from inside the MFMA stream (its address arithmetic runs in the matrix pipe's shadow), always:
-      // past the band it brings zeros / unused rows into ring slots that are dead by then, which keeps vmcnt uniform
-      issue_next((S + 3) & 3, (S + 3) & 3);                   // row r + 3
+      // Row r+3 is fetched from inside the MFMA stream, always: past the band it brings zeros / unused rows into ring slots that
+      // are dead by then, which keeps vmcnt uniform.  Its ring slot held row r-1, whose last reads returned before the barrier
+      // of step r-1.
+      constexpr int SN = (S + 3) & 3;
+      auto none = [](int) {};
+      load_x(S, 1, xb);                                       // the next tap column's fragments first, then this one's MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+      mfma12(0, xa, [&](int kh) { if (kh < 2) issue_next_piece(kh, SN, SN); });
       load_x(S, 2, xa);
-      mfma12(1, xb);
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
-      __builtin_amdgcn_sched_group_barrier(0x008, 12, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma12(1, xb, [&](int kh) { if (kh == 0) issue_next_piece(2, SN, SN); });
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every read of X row r has returned: its slot is reused by row r+4
       wait_vmcnt<3>();                                        // rows <= r+2 have landed
@@ -222,9 +229,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args 
       const int on = r + 2 < yb ? X_BYTES + ((S + 2) & 3) * DROW : ZERO_IMG;      // dY row r+2 (or the zero image)
       load_x((S + 1) & 3, 0, xb);                             // (past the last row: harmless reads, never used)
       load_dy(on, dn);
-      mfma12(2, xa);
-      __builtin_amdgcn_sched_group_barrier(0x100, 8, 2);
-      __builtin_amdgcn_sched_group_barrier(0x008, 12, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma12(2, xa, none);
 #pragma unroll
       for (int ao = 0; ao < 2; ++ao) {
         dm[ao] = dc[ao];
@@ -252,6 +258,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args 
     __builtin_amdgcn_s_barrier();                  // the next item's DMA overwrites the slots read last
   }
 
+  mfma_results_ready();                              // (in-place asm MFMAs: the wait states in front of the stores' reads are ours)
   float* __restrict__ ws = a.ws + (size_t)by * a.Co * 9 * a.Ci;
 #pragma unroll
   for (int t = 0; t < 9; ++t)

@@ -365,3 +365,35 @@ def test_counted_vmcnt_matches_drained_build(tmp_path):
         assert np.array_equal(a[k], b[k]), k
         if k.endswith("0"):
             assert np.array_equal(a[k], a[k[:-1] + "1"]) and np.array_equal(a[k], a[k[:-1] + "2"]), k
+
+
+def test_buffer_descriptor_dma_zero_fills_out_of_range_lanes():
+    """dma16_buf (csrc/dma.hpp): the LDS-DMA pieces of the 512-thread kernels go through a buffer descriptor, and padding is the
+    hardware's range check — a lane with the always-out-of-range offset, or any lane under a num_records = 0 descriptor, must
+    write ZEROS to its 16-byte LDS slot (not skip it), in-range lanes their data, and the scalar offset must move the source."""
+    import ctypes, os
+    here = os.path.dirname(os.path.abspath(__file__))
+    so = os.path.join(os.path.dirname(here), "medical-image-segmentation-and-classification_amd", "mi355", "libmi355probe.so")
+    assert os.path.exists(so), "libmi355probe.so not built (make -C csrc)"
+    probe = ctypes.CDLL(so)
+    probe.mi355_probe_bufdma.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_ulonglong, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    src = torch.arange(1, 1025, dtype=torch.int32, device=DEV)               # 4 KiB, no zero word anywhere
+    out = torch.empty(256, dtype=torch.int32, device=DEV)
+
+    def run(soff, mask, valid):
+        assert probe.mi355_probe_bufdma(src.data_ptr(), soff, mask, valid, out.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        return out.cpu().view(64, 4)
+
+    got = run(0, 0, 1)
+    assert torch.equal(got, src[:256].cpu().view(64, 4))
+    got = run(2048, 0, 1)                                                    # scalar offset: the second half of the buffer
+    assert torch.equal(got, src[512:768].cpu().view(64, 4))
+    mask = 0xF0F0_0000_0000_FF01
+    got = run(1024, mask, 1)
+    ref = src[256:512].cpu().view(64, 4).clone()
+    for lane in range(64):
+        if (mask >> lane) & 1:
+            ref[lane] = 0
+    assert torch.equal(got, ref)
+    assert int(run(0, 0, 0).abs().sum()) == 0                                # num_records = 0: the whole piece is zeros

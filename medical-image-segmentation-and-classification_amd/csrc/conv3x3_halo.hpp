@@ -79,8 +79,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_rw_kernel(const ConvArgs 
 
   // ---- DMA lane geometry: a 1-KiB instruction = 16 patch pixels x 64 B; wave w issues pieces w, w+4, ... (P_IT of them; a
   // piece index past the patch repeats the last piece: same bytes to the same place, so every wave issues the same count) ----
+  // Sources go through buffer descriptors (dma.hpp: dma16_buf): base = this image / this channel tile's weight rows (wave-
+  // uniform), a scalar offset for the slab (and tap), ONE 32-bit register per piece for the lane's offset — the always-out-of-
+  // range offset where the lane is padding, so that the hardware's range check writes the zeros.
   const int lrow = lane >> 2, slot = lane & 3;
-  const T* p_src[P_IT];
+  const bufdesc_t desc_in = make_buf(in + (size_t)n * a.Hi * a.Wi * a.ldi);
+  unsigned p_off[P_IT];
   int p_dst[P_IT];
 #pragma unroll
   for (int i = 0; i < P_IT; ++i) {
@@ -89,25 +93,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_rw_kernel(const ConvArgs 
     const int py = q / PW, px = q - py * PW;
     const int yy = y0 - 1 + py, xx = x0 - 1 + px;
     const bool ok = q < NPIX && (unsigned)yy < (unsigned)a.Hlog && (unsigned)xx < (unsigned)a.Wlog;
-    p_src[i] = ok ? in + ((size_t)(n * a.Hi + (yy >> a.up)) * a.Wi + (xx >> a.up)) * a.ldi + (slot ^ (((q >> 2) & 1) << 1)) * EPC
-                  : nullptr;
+    p_off[i] = ok ? (unsigned)((((yy >> a.up) * a.Wi + (xx >> a.up)) * a.ldi + (slot ^ (((q >> 2) & 1) << 1)) * EPC) * 2) : DMA_PAD;
     p_dst[i] = piece * 1024;
   }
+  const unsigned lds0 = lds_addr(lds);               // LDS byte address of the ring (DMA destinations are integers)
   unsigned char* const patch0 = lds;
   unsigned char* const bring = lds + 2 * PATCH_BYTES;
   auto issue_patch_piece = [&](int buf, int c0, int i) {
-    const char* p = p_src[i] ? reinterpret_cast<const char*>(p_src[i] + c0) : zero + slot * 16;
-    dma16(p, lds_addr(patch0 + buf * PATCH_BYTES + p_dst[i]));
+    dma16_buf(desc_in, p_off[i], (unsigned)c0 * 2u, lds0 + buf * PATCH_BYTES + p_dst[i]);
   };
   // stage = the three taps of patch column pw: slab ph holds tap (ph, pw), mirrored for the data gradient; a wave
   // brings 16 rows x 64 B of each slab (one instruction per slab)
   const size_t wrow = (size_t)9 * a.Ci;
   const int brow = wave * 16 + lrow;
-  const T* const b_src = wk + (size_t)(n0 + brow) * wrow + (slot ^ (((brow >> 2) & 1) << 1)) * EPC;
+  const bufdesc_t desc_w = make_buf(wk + (size_t)n0 * wrow), desc_none = make_buf(wk, false);
+  const unsigned b_off = (unsigned)(((size_t)brow * wrow + (slot ^ (((brow >> 2) & 1) << 1)) * EPC) * 2);
   auto issue_stage_piece = [&](int stage, int pw, int c0, int ph) {      // c0 < 0: nothing left to fetch (zeros into a dead slot)
     const int tap = flip ? (2 - ph) * 3 + (2 - pw) : ph * 3 + pw;
-    const char* p = c0 >= 0 ? reinterpret_cast<const char*>(b_src + (size_t)tap * a.Ci + c0) : zero + slot * 16;
-    dma16(p, lds_addr(bring + stage * STAGE + wave * 1024 + ph * SLAB));
+    dma16_buf(c0 >= 0 ? desc_w : desc_none, b_off, (unsigned)(tap * a.Ci + c0) * 2u, lds0 + 2 * PATCH_BYTES + stage * STAGE + wave * 1024 + ph * SLAB);
   };
 
   // ---- fragment geometry ------------------------------------------------------------------------------------------

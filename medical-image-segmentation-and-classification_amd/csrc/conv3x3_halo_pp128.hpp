@@ -80,8 +80,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pp128_kernel(const ConvArgs 
 
   // ---- DMA lane geometry (a 1-KiB instruction = 16 patch pixels x 64 B; wave w issues patch pieces w, w+8, ...) ----------
   const int lrow = lane >> 2, slot = lane & 3;
-  // per-lane source of every patch piece as a 32-bit BYTE offset inside image n (0xffffffff: padding -> zero page); the image
-  // base and the piece's LDS destination are wave-uniform (scalar registers)
+  // per-lane source of every patch piece as a 32-bit BYTE offset inside image n (DMA_PAD: padding); the image base and the
+  // piece's LDS destination are wave-uniform (scalar registers)
   const char* const img = reinterpret_cast<const char*>(in + (size_t)n * a.Hi * a.Wi * a.ldi);
   unsigned p_off[P_IT + 1];                          // ([P_IT]: the left-over piece, used by wave 0 only)
 #pragma unroll
@@ -91,27 +91,18 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pp128_kernel(const ConvArgs 
     const int py = q / PWL, px = q - py * PWL;
     const int yy = y0 - 1 + py, xx = x0 - 1 + px;
     const bool ok = q < NPIX && px < PW && (unsigned)yy < (unsigned)a.Hlog && (unsigned)xx < (unsigned)a.Wlog;
-    p_off[i] = ok ? (unsigned)((((yy >> a.up) * a.Wi + (xx >> a.up)) * a.ldi + (slot ^ (((q >> 2) & 1) << 1)) * EPC) * 2) : 0xffffffffu;
+    p_off[i] = ok ? (unsigned)((((yy >> a.up) * a.Wi + (xx >> a.up)) * a.ldi + (slot ^ (((q >> 2) & 1) << 1)) * EPC) * 2) : DMA_PAD;
   }
   const unsigned lds0 = lds_addr(lds);               // LDS byte address of the ring (DMA destinations are integers)
   unsigned char* const patch0 = lds;
   unsigned char* const bring = lds + Cfg::NPB * PATCH_BYTES;
-  // padding lanes take no part in the DMA (EXEC off): their 16-byte slots of both patch buffers are zeroed ONCE, below — a
-  // slot that is padding for one slab of this tile is padding for all of them.  Source = scalar base (image + slab) + the lane's
-  // 32-bit offset: no 64-bit address is ever formed in vector registers.
+  // Patch pieces go through a buffer descriptor on the image (dma.hpp: dma16_buf): a padding lane carries the always-out-of-range
+  // offset and the hardware's range check writes its zeros — no zero page, no EXEC masking, no 64-bit address in vector registers.
+  const bufdesc_t desc_in = make_buf(img);
   auto issue_patch_piece = [&](int buf, int c0, int i) __attribute__((always_inline)) {
-    const unsigned o = p_off[i];
     const int piece = i < P_IT ? wave + 8 * i : P_INSTR - 1;
-    if (o != 0xffffffffu) dma16_sv_m0(img + c0 * 2, o, lds0 + buf * PATCH_BYTES + piece * 1024);
+    dma16_buf(desc_in, p_off[i], (unsigned)c0 * 2u, lds0 + buf * PATCH_BYTES + piece * 1024);
   };
-#pragma unroll
-  for (int i = 0; i <= P_IT; ++i)
-    if (p_off[i] == 0xffffffffu && (i < P_IT || wave == 0)) {
-      const int piece = i < P_IT ? wave + 8 * i : P_INSTR - 1;
-#pragma unroll
-      for (int b = 0; b < Cfg::NPB; ++b)
-        *reinterpret_cast<uint4*>(patch0 + b * PATCH_BYTES + piece * 1024 + lane * 16) = uint4{0u, 0u, 0u, 0u};
-    }
   // weight stage = the three taps (ph = 0, 1, 2) of patch column pw, 8 KiB each = eight 1-KiB pieces of 16 rows: wave w brings
   // rows [16 w, +16) of all three slabs.
   const size_t wrow = (size_t)9 * a.Ci;
@@ -169,7 +160,6 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pp128_kernel(const ConvArgs 
   issue_stage(0, 0, 0);
   issue_stage(1, 1, 0);
   wait_vmcnt<3>();                                                                // all but stage 1
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                              // (the padding zeros)
   __builtin_amdgcn_s_barrier();
 
   // A step s = (slab chunk, patch column pw) runs as TWO sub-steps h = 0, 1 over the channel blocks {2h, 2h+1} of the wave's four:

@@ -236,7 +236,8 @@ extern "C" int mi355_conv2d_wgrad_splits(int N, int Ho, int Wo, int Ci, int Co, 
     // half of every SIMD's registers to the main stream's kernels, the two interleave instead of queueing, and half as many
     // partial slabs reach the reduce.  Step: 512 / 384 / 320 / 256 / 192 / 128 workgroups = 18.53 / 18.58 / 18.47 / 18.18 /
     // 18.28 / 19.28 ms.
-    long long s = 256 / tiles;
+    static const int wgs = getenv("MI355_WGRAD_WGS") ? atoi(getenv("MI355_WGRAD_WGS")) : 256;      // (A/B switch)
+    long long s = wgs / tiles;
     if (s > items) s = items;
     const long long slab = (long long)Co * 9 * Ci * 4;
     while (s > 1 && s * slab > (512ll << 20)) --s;
@@ -270,6 +271,22 @@ static int wgrad_launch(const WgradArgs& a, int splits, hipStream_t s) {
     hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64>), grid, dim3(256), 0, s, a);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
+}
+
+template <typename T, bool W16>
+static int launch_wgrad3x3(const Wgrad3Args& h, dim3 grid, hipStream_t s) {
+  constexpr int lds_bytes = Wgrad3Lds<W16>::BYTES;
+  static const hipError_t configured =
+      hipFuncSetAttribute((const void*)wgrad3x3_halo_kernel<T, W16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (configured != hipSuccess)
+    MI355_FAIL((int)configured, "wgrad3x3_halo: cannot reserve %d B of LDS: %s", lds_bytes, hipGetErrorString(configured));
+  hipLaunchKernelGGL((wgrad3x3_halo_kernel<T, W16>), grid, dim3(256), lds_bytes, s, h);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
+static int launch_wgrad3x3_any(const Wgrad3Args& h, dim3 grid, int hmode, int dtype, hipStream_t s) {
+  if (hmode == 2) return dtype == MI355_F16 ? launch_wgrad3x3<f16_t, true>(h, grid, s) : launch_wgrad3x3<bf16_t, true>(h, grid, s);
+  return dtype == MI355_F16 ? launch_wgrad3x3<f16_t, false>(h, grid, s) : launch_wgrad3x3<bf16_t, false>(h, grid, s);
 }
 
 extern "C" int mi355_conv2d_wgrad(const void* x, const void* dy, float* ws, int splits, int N, int Hi, int Wi, int Ci,
@@ -306,15 +323,7 @@ extern "C" int mi355_conv2d_wgrad(const void* x, const void* dy, float* ws, int 
     h.items_per_app = h.items;
     h.items_per_block = ceil_div(h.items, splits);
     dim3 grid(ceil_div(Co, 64) * ceil_div(Ci, 64), splits);
-    if (hmode == 2) {
-      if (dtype == MI355_F16) hipLaunchKernelGGL((wgrad3x3_halo_kernel<f16_t, true>), grid, dim3(256), 0, (hipStream_t)s, h);
-      else hipLaunchKernelGGL((wgrad3x3_halo_kernel<bf16_t, true>), grid, dim3(256), 0, (hipStream_t)s, h);
-    } else {
-      if (dtype == MI355_F16) hipLaunchKernelGGL((wgrad3x3_halo_kernel<f16_t, false>), grid, dim3(256), 0, (hipStream_t)s, h);
-      else hipLaunchKernelGGL((wgrad3x3_halo_kernel<bf16_t, false>), grid, dim3(256), 0, (hipStream_t)s, h);
-    }
-    MI355_LAUNCH_CHECK();
-    return MI355_OK;
+    return launch_wgrad3x3_any(h, grid, hmode, dtype, (hipStream_t)s);
   }
   return dispatch_dtype(dtype, "conv2d_wgrad", [&](auto tag) { return wgrad_launch<decltype(tag)>(a, splits, (hipStream_t)s); });
 }
@@ -351,15 +360,7 @@ extern "C" int mi355_conv2d_wgrad_multi(const void* x0, const void* dy0, const v
   MI355_CHECK_ARG(splits <= h.items, "conv2d_wgrad_multi: more splits (%d) than work items (%d)", splits, h.items);
   h.items_per_block = ceil_div(h.items, splits);
   dim3 grid(ceil_div(Co, 64) * ceil_div(Ci, 64), splits);
-  if (hmode == 2) {
-    if (dtype == MI355_F16) hipLaunchKernelGGL((wgrad3x3_halo_kernel<f16_t, true>), grid, dim3(256), 0, (hipStream_t)s, h);
-    else hipLaunchKernelGGL((wgrad3x3_halo_kernel<bf16_t, true>), grid, dim3(256), 0, (hipStream_t)s, h);
-  } else {
-    if (dtype == MI355_F16) hipLaunchKernelGGL((wgrad3x3_halo_kernel<f16_t, false>), grid, dim3(256), 0, (hipStream_t)s, h);
-    else hipLaunchKernelGGL((wgrad3x3_halo_kernel<bf16_t, false>), grid, dim3(256), 0, (hipStream_t)s, h);
-  }
-  MI355_LAUNCH_CHECK();
-  return MI355_OK;
+  return launch_wgrad3x3_any(h, grid, hmode, dtype, (hipStream_t)s);
 }
 
 

@@ -29,6 +29,11 @@ struct Wgrad3Args {
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
 
+template <bool W16> struct Wgrad3Lds {              // dynamic LDS of wgrad3x3_halo_kernel (shared with its launchers)
+  static constexpr int NR = 8;
+  static constexpr int BYTES = NR * ((W16 ? 48 : 40) * 128 + 32 * 128) + 4096;
+};
+
 // ---- v_mfma_f32_16x16x32, dY rows held in registers ----------------------------------------------------------------
 // The MFMA consumes a whole 32-pixel row segment per instruction and
 // the wave tile is 2 x 2 blocks of 16 x 16 (the chip holds a higher clock on this shape, MI355X_MICROARCH.md DVFS
@@ -50,10 +55,20 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args 
   static_assert(sizeof(T) == 2, "bf16 / fp16 only");
   constexpr int XPX = W16 ? 48 : 40, XROW = XPX * 128, DROW = 32 * 128;
   constexpr int XPIECES = XPX / 8;                   // 1-KiB DMA pieces per X row: waves 0..3, then waves 0 .. XPIECES-5
-  constexpr int NRX = 4, NRD = 4;      // equal ring depths: X row q and dY row q share the slot index (q - (ya-1)) & 3
+  // Rings of NR rows, row r + PF fetched during step r (its slot held row r - 1).  PF = 3 left the waves waiting at the
+  // counted vmcnt of every step (a timing-only build without the per-step wait + barrier ran 10-18 % faster, and exactly as
+  // fast as the no-DMA build once the DMA was gone too: the wait was for rows, not for waves) — a row step is ~0.4 us, an
+  // LDS-DMA row under load takes longer than three of them.  Equal ring depths: X row q and dY row q share the slot index.
+#ifndef WG3_PF
+#define WG3_PF 7
+#endif
+  constexpr int NR = Wgrad3Lds<W16>::NR, PF = WG3_PF;
+  static_assert(PF >= 3 && PF < NR, "row r + PF lands in the slot of a row <= r - 1");
+  constexpr int NRX = NR, NRD = NR;
   constexpr int X_BYTES = NRX * XROW, D_BYTES = NRD * DROW;
   constexpr int ZERO_IMG = X_BYTES + D_BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[X_BYTES + D_BYTES + 4096];
+  static_assert(Wgrad3Lds<W16>::BYTES == X_BYTES + D_BYTES + 4096, "launcher and kernel disagree on the LDS size");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* const xr = lds;
   unsigned char* const dr = lds + X_BYTES;
   unsigned char* const dump = lds + ZERO_IMG;
@@ -182,8 +197,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args 
     // The rows the main loop fetches are CONSECUTIVE (ya + 2, ya + 3, ...): their per-lane source pointers advance by a row
     // stride instead of being rebuilt from (n, r, x) with 64-bit multiplies each time, and the lane part of the bounds test
     // (channel / image-column range) is taken once per item; only the row part, wave-uniform, is evaluated per row.
-    unsigned d_soff_next = (unsigned)(ya + 2) * d_stride, x_soff_next = (unsigned)((ya + 2) >> a.up) * x_stride;      // scalar registers
-    int r_next = ya + 2;
+    unsigned d_soff_next = (unsigned)(ya - 1 + PF) * d_stride, x_soff_next = (unsigned)((ya - 1 + PF) >> a.up) * x_stride;      // scalar registers
+    int r_next = ya - 1 + PF;
     auto issue_next_piece = [&](int piece, int xs, int ds) {      // row r_next into ring slots xs / ds; the last piece advances
 #ifndef WG3_T_NODMA                                            // (timing-only build: stale rows, the no-DMA ceiling of the loop)
       issue_piece(piece, r_next, d_soff_next, x_soff_next, xs, ds);
@@ -196,10 +211,9 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args 
     };
 
     // ring slots: X row q -> (q - (ya-1)) mod NRX, dY row q -> (q - (ya-1)) mod NRD
-    issue_row(ya - 1, 0, 0);
-    issue_row(ya, 1, 1);
-    issue_row(ya + 1, 2, 2);
-    wait_vmcnt<3>();
+#pragma unroll
+    for (int k = 0; k < PF; ++k) issue_row(ya - 1 + k, k, k);
+    wait_vmcnt<3 * (PF - 3)>();                    // rows ya - 1, ya, ya + 1 have landed
     __builtin_amdgcn_s_barrier();
 
     bf16x8 xa[2], xb[2];
@@ -211,10 +225,10 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args 
     // constant (four step bodies per trip), so every LDS offset of the step is an instruction immediate.
     auto row_step = [&](int r, auto slot_tag, bf16x8 (&xa)[2], bf16x8 (&xb)[2]) {
       constexpr int S = decltype(slot_tag)::value;
-      // Row r+3 is fetched from inside the MFMA stream, always: past the band it brings zeros / unused rows into ring slots that
-      // are dead by then, which keeps vmcnt uniform.  Its ring slot held row r-1, whose last reads returned before the barrier
-      // of step r-1.
-      constexpr int SN = (S + 3) & 3;
+      // Row r + PF is fetched from inside the MFMA stream, always: past the band it brings zeros (a descriptor with no records:
+      // no memory access) into ring slots that are dead by then, which keeps vmcnt uniform.  Its ring slot held row r - 1, whose
+      // last reads returned before the barrier of step r - 1.
+      constexpr int SN = (S + PF) % NR;
       auto none = [](int) {};
       load_x(S, 1, xb);                                       // the next tap column's fragments first, then this one's MFMAs
       __builtin_amdgcn_sched_barrier(0);
@@ -223,11 +237,13 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args 
       __builtin_amdgcn_sched_barrier(0);
       mfma12(1, xb, [&](int kh) { if (kh == 0) issue_next_piece(2, SN, SN); });
       __builtin_amdgcn_sched_barrier(0);
+#ifndef WG3_T_NOBARRIER                                        // (timing-only build: what the per-row synchronisation costs)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every read of X row r has returned: its slot is reused by row r+4
-      wait_vmcnt<3>();                                        // rows <= r+2 have landed
+      wait_vmcnt<3 * (PF - 2)>();                             // rows <= r+2 have landed
       __builtin_amdgcn_s_barrier();
-      const int on = r + 2 < yb ? X_BYTES + ((S + 2) & 3) * DROW : ZERO_IMG;      // dY row r+2 (or the zero image)
-      load_x((S + 1) & 3, 0, xb);                             // (past the last row: harmless reads, never used)
+#endif
+      const int on = r + 2 < yb ? X_BYTES + ((S + 2) % NR) * DROW : ZERO_IMG;      // dY row r+2 (or the zero image)
+      load_x((S + 1) % NR, 0, xb);                            // (past the last row: harmless reads, never used)
       load_dy(on, dn);
       __builtin_amdgcn_sched_barrier(0);
       mfma12(2, xa, none);
@@ -242,14 +258,23 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const Wgrad3Args 
     using S1 = std::integral_constant<int, 1>;
     using S2 = std::integral_constant<int, 2>;
     using S3 = std::integral_constant<int, 3>;
-    int r = ya - 1;                                 // RB is even: RB + 2 row steps; the X register sets swap every step
-    for (; r + 3 <= yb; r += 4) {
+    using S4 = std::integral_constant<int, 4>;
+    using S5 = std::integral_constant<int, 5>;
+    using S6 = std::integral_constant<int, 6>;
+    using S7 = std::integral_constant<int, 7>;
+    static_assert(NR == 8, "eight step bodies per trip");
+    int r = ya - 1;                                 // RB in {8, 16, 32}: RB + 2 row steps; the X register sets swap every step
+    for (; r + 7 <= yb; r += 8) {
       row_step(r, S0{}, xa, xb);
       row_step(r + 1, S1{}, xb, xa);
       row_step(r + 2, S2{}, xa, xb);
       row_step(r + 3, S3{}, xb, xa);
+      row_step(r + 4, S4{}, xa, xb);
+      row_step(r + 5, S5{}, xb, xa);
+      row_step(r + 6, S6{}, xa, xb);
+      row_step(r + 7, S7{}, xb, xa);
     }
-    if (r <= yb) {                                  // (RB + 2) % 4 == 2: the ring is back at slot 0 here
+    if (r <= yb) {                                  // (RB + 2) % 8 == 2: the ring is back at slot 0 here
       row_step(r, S0{}, xa, xb);
       row_step(r + 1, S1{}, xb, xa);
     }

@@ -58,7 +58,8 @@ for k in sorted(fetch, key=lambda k: -(2 * fetch[k] + write.get(k, 0))):
     # bench.py tags drop the element type of the templated kernels
     tag = re.sub(r"<bf16,|<f16,", "<", k) if ("halo" in k or "dma" in k or "stream" in k) else k
     tag = tag.replace("<bf16>", "").replace("<f16>", "")
-    tag = re.sub(r"^(wgrad3x3_halo_kernel)<[01]>$", r"\1", tag)      # (W16 flag of the nine-tap weight gradient: one bench tag)
+    if tag.startswith("wgrad3x3_halo_kernel"):      # (both W16 instantiations of the nine-tap weight gradient: one bench tag)
+        tag = "wgrad3x3_halo_kernel"
     e = {"launches_profiled": nf[k], "fetch_MB_per_launch": round(f, 1), "write_MB_per_launch": round(w, 1),
          "hbm_MB_per_launch": round(f + w, 1)}
     if tag in out["kernels"]:                      # two instantiations under one bench tag: launch-weighted mean

@@ -42,6 +42,9 @@ CASES = [  # N, Ci, H, W, Co, K, stride, pad, up
     (1, 192, 16, 32, 128, 3, 1, 1, 0),
     (2, 64, 8, 16, 128, 3, 1, 1, 1),
     (1, 128, 48, 32, 128, 3, 1, 1, 0),
+    # ... and more tiles than CUs (36 x 4 x 2 = 288): persistent workgroups that run two tiles, the second one's prologue in
+    # flight during the first one's epilogue
+    (36, 64, 32, 64, 256, 3, 1, 1, 0),
 ]
 
 
@@ -92,31 +95,33 @@ def test_conv_dgrad(case, dtype):
     assert rel_err(from_nhwc(dx), ref) < TOL[dtype]
 
 
-@pytest.mark.parametrize("hw", [(8, 8), (16, 32), (32, 32)])          # generic / ping-pong halo kernel (one and two tiles per image)
+# (8, 8): generic kernel; (16, 32) / (32, 32): halo kernels, one and two tiles per image; 256 -> 128 channels on 32 x 64 (four tiles of
+# the 128-channel ping-pong kernel per image, persistent workgroups running several tiles each when the batch is large)
+@pytest.mark.parametrize("hw,ci,co,n", [((8, 8), 32, 64, 2), ((16, 32), 32, 64, 2), ((32, 32), 32, 64, 2), ((32, 64), 256, 128, 2),
+                                        ((16, 32), 256, 256, 3)])
 @pytest.mark.parametrize("dtype", DT)
-def test_conv_strided_slices_and_accumulate(dtype, hw):
+def test_conv_strided_slices_and_accumulate(dtype, hw, ci, co, n):
     """input read from / output written into channel slices of wider buffers; accumulate flag; ReLU epilogue."""
-    n, ci, co = 2, 32, 64
     h, w_ = hw
     g = torch.Generator().manual_seed(3)
-    x = torch.randn(n, ci, h, w_, generator=g); w = torch.randn(co, ci, 3, 3, generator=g) * 0.1
+    x = torch.randn(n, ci, h, w_, generator=g); w = torch.randn(co, ci, 3, 3, generator=g) * (0.1 * (32 / ci) ** 0.5)
     ref = F.conv2d(q(x, dtype), q(w, dtype), None, padding=1)
-    xin = torch.zeros(n, h, w_, 96, dtype=dtype, device=DEV); xin[..., 64:] = to_nhwc(x, dtype)
+    xin = torch.zeros(n, h, w_, ci + 64, dtype=dtype, device=DEV); xin[..., 64:] = to_nhwc(x, dtype)
     wf, _ = pack_w(w, dtype)
-    base = torch.randn(n, h, w_, 160, generator=g).to(dtype)
+    base = torch.randn(n, h, w_, co + 96, generator=g).to(dtype)
     out = base.clone().to(DEV)
     es = out.element_size()
-    lib.mi355_conv2d_igemm(xin.data_ptr() + 64 * es, wf, None, out.data_ptr() + 32 * es, n, h, w_, ci, 96, h, w_, co,
-                           160, 3, 3, 1, 1, -1, 1, 0, 1, None, DTYPE_CODE[dtype])
+    lib.mi355_conv2d_igemm(xin.data_ptr() + 64 * es, wf, None, out.data_ptr() + 32 * es, n, h, w_, ci, ci + 64, h, w_, co,
+                           co + 96, 3, 3, 1, 1, -1, 1, 0, 1, None, DTYPE_CODE[dtype])
     torch.cuda.synchronize()
     got = out.float().cpu()
-    exp = base.float().clone(); exp[..., 32:96] += ref.permute(0, 2, 3, 1)
-    assert rel_err(got[..., 32:96], q(exp[..., 32:96], dtype)) < TOL[dtype]
-    assert torch.equal(got[..., :32], base.float()[..., :32]) and torch.equal(got[..., 96:], base.float()[..., 96:])
+    exp = base.float().clone(); exp[..., 32:32 + co] += ref.permute(0, 2, 3, 1)
+    assert rel_err(got[..., 32:32 + co], q(exp[..., 32:32 + co], dtype)) < TOL[dtype]
+    assert torch.equal(got[..., :32], base.float()[..., :32]) and torch.equal(got[..., 32 + co:], base.float()[..., 32 + co:])
     if dtype != torch.float32:                                  # ReLU in the epilogue (bit 1), with a bias
         b = torch.randn(co, generator=g)
         y = torch.empty(n, h, w_, co, dtype=dtype, device=DEV)
-        lib.mi355_conv2d_igemm(xin.data_ptr() + 64 * es, wf, b.to(DEV), y, n, h, w_, ci, 96, h, w_, co, co, 3, 3, 1, 1, -1, 1, 0, 2, None,
+        lib.mi355_conv2d_igemm(xin.data_ptr() + 64 * es, wf, b.to(DEV), y, n, h, w_, ci, ci + 64, h, w_, co, co, 3, 3, 1, 1, -1, 1, 0, 2, None,
                                DTYPE_CODE[dtype])
         torch.cuda.synchronize()
         assert rel_err(from_nhwc(y), torch.relu(ref + b.view(1, -1, 1, 1))) < TOL[dtype]
@@ -229,7 +234,7 @@ def test_conv_wgrad(case, dtype):
 
 
 @pytest.mark.parametrize("case", [(2, 64, 16, 32, 128, 3, 1, 1, 0), (2, 96, 32, 64, 64, 3, 1, 1, 0), (2, 96, 16, 16, 64, 3, 1, 1, 0), (3, 64, 9, 7, 64, 1, 1, 0, 0),
-                                  (2, 128, 32, 64, 256, 3, 1, 1, 0),
+                                  (2, 128, 32, 64, 256, 3, 1, 1, 0), (36, 64, 32, 64, 256, 3, 1, 1, 0),
                                   (2, 64, 8, 16, 128, 3, 1, 1, 1), (1, 32, 5, 5, 128, 3, 2, 1, 0)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_conv_fused_bn_statistics(case, dtype):
@@ -334,7 +339,7 @@ def test_128_channel_ping_pong_variant_passes_the_same_cases():
     r = subprocess.run([sys.executable, "-c", probe], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("6"), (r.stdout, r.stderr[-2000:])       # IG_HALO_PP128
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
-                        "fwd or dgrad or statistics or upsampled"], env=env, capture_output=True, text=True, timeout=600)
+                        "fwd or dgrad or statistics or upsampled or slices"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:]
     code = DTYPE_CODE[torch.bfloat16]
     assert lib.mi355_conv2d_igemm_variant(32, 64, 256, 32, 64, 128, 3, 3, 1, 1, -1, 1, 0, code) == 6

@@ -12,6 +12,8 @@ static __device__ uint4 g_zero_page[16];   // 256 B of zeros: DMA source for pad
 // bit for bit — a wrong count shows up as a difference, not as a hang).
 #ifdef MI355_DMA_DRAIN
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#elif defined(MI355_T_NOWAIT)      // timing-only build (stale operands): what the counted waits cost
+template <int N> __device__ __forceinline__ void wait_vmcnt() { if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #else
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 #endif

@@ -544,7 +544,7 @@ static IgemmVariant pick_variant(int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
     if (use_pp && Wo % 32 == 0 && Ho % 16 == 0) return IG_HALO_PP;
     // 16 x 32 pixels x 128 channels, ping-pong halves (conv3x3_halo_pp128.hpp): half the operand bytes per FLOP; one workgroup
     // per CU, so only where the reduction is deep enough to amortise a tile's prologue and epilogue.  Measured per layer
-    // (profiles/r02b_conv_layers_*): Ci >= 512 +10-14 %, Ci = 256 +4-7 %, Ci = 128 -2..+2 % -> threshold 256.
+    // (profiles/r02c_conv_layers.txt against r02a_conv_layers_pp0.txt): Ci >= 512 +14-17 %, Ci = 256 +7-9 %, Ci = 128 -2..+2 % -> threshold 256.
     // MI355_HALO_PP128=0 switches it off (A/B), MI355_HALO_PP128_MINCI moves the threshold.
     static const int pp128 = getenv("MI355_HALO_PP128") ? atoi(getenv("MI355_HALO_PP128")) : 1;
     static const int pp128_min_ci = getenv("MI355_HALO_PP128_MINCI") ? atoi(getenv("MI355_HALO_PP128_MINCI")) : 256;

@@ -109,7 +109,8 @@ template <typename T> struct RowdotBwdOp {
 #pragma unroll
     for (int e = 0; e < EPC; ++e) wr[e] = w[c0 + e];
   }
-  static constexpr int FETCH_ROWS = 4;        // (rowred.hpp: rows fetched before any is finished; one workgroup per CU)
+  static constexpr int FETCH_ROWS = 4;        // (rowred.hpp: rows fetched before any is finished)
+  static constexpr int MAX_WGS = 1024;        // one fp32 + one 2-byte stream per row: more workgroups than the BN reductions' one per CU
   struct In { Vec16<T> v; float d; };
   __device__ In fetch(size_t row, int c0) const {
     return In{ld16<T>(x + row * ldx + c0), dz[K == 1 ? row : row + (row / hw) * (size_t)(K - 1) * hw]};

@@ -7,6 +7,7 @@
 // workgroup:  partial[(block*NQ + q)*C + c].  A tiny finalize kernel sums the partials in a
 // fixed order (deterministic, no float atomics).
 #pragma once
+#include <stdlib.h>
 #include <type_traits>
 #include "common.hpp"
 
@@ -43,6 +44,8 @@ static inline RowRedGeom rowred_geom(long long M, int C, int nblocks) {
 
 // An op may split apply() into `In fetch(row, c0) const` (loads only) and `finish(in, row, c0[, acc])` (arithmetic and stores),
 // with `static constexpr int FETCH_ROWS`: the kernels then fetch that many rows before finishing any of them.
+template <typename Op, typename = void> struct has_max_wgs : std::false_type {};
+template <typename Op> struct has_max_wgs<Op, std::void_t<decltype(Op::MAX_WGS)>> : std::true_type {};
 template <typename Op, typename = void> struct has_fetch : std::false_type {};
 template <typename Op> struct has_fetch<Op, std::void_t<typename Op::In>> : std::true_type {};
 
@@ -147,7 +150,13 @@ static inline int rowred_launch(const Op& op, long long M, int C, float* partial
   // 4.97 / 5.03 / 5.35 TB/s); the rows of `partial` they do not produce are zero-filled.
   const int nb_rows = rowreduce_blocks(M);
   int nb = nb_rows;
-  if constexpr (has_fetch<Op>::value) nb = nb < 256 ? nb : 256;
+  static const int rr_wgs = getenv("MI355_RR_WGS") ? atoi(getenv("MI355_RR_WGS")) : 0;      // (A/B switch: one cap for every op)
+  if constexpr (has_fetch<Op>::value) {
+    int cap = 256;
+    if constexpr (has_max_wgs<Op>::value) cap = Op::MAX_WGS;      // (narrow rows: rowdot_bwd 256 / 512 / 1024 workgroups = 0.307 / 0.218 / 0.212 ms per step)
+    if (rr_wgs > 0) cap = rr_wgs;
+    nb = nb < cap ? nb : cap;
+  }
   RowRedGeom g = rowred_geom<T>(M, C, nb);
   g.nb_rows = nb_rows;
   const int cp = C / epc;
@@ -209,7 +218,8 @@ static inline int rowmap_launch(const Op& op, long long M, int C, hipStream_t s)
   long long blocks = (M + rpb - 1) / rpb;
   // grid-stride beyond 16 workgroups per CU; ops that keep several rows in flight per thread stream faster from 4 per CU
   // (bn_act 256^2 x 64: 4096 / 1024 / 512 workgroups = 4.18 / 4.45 / 4.45 TB/s)
-  const long long cap = has_fetch<Op>::value ? 256 * 4 : 256 * 16;
+  static const int rm_wgs = getenv("MI355_RM_WGS") ? atoi(getenv("MI355_RM_WGS")) : 256 * 4;      // (A/B switch)
+  const long long cap = has_fetch<Op>::value ? rm_wgs : 256 * 16;
   if (blocks > cap) blocks = cap;     // grid-stride beyond 16 workgroups per CU
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL((rowmap_kernel<T, Op>), dim3((int)blocks), dim3(256), 0, s, op, M, cp);

@@ -216,7 +216,7 @@ template <typename T> struct BnActOp {
   struct In { Vec16<T> v, v2, vr; };
   __device__ In fetch(size_t row, int c0) const {
     In in;
-    in.v = ld16<T>(x + row * ldx + c0);
+    in.v = ld16_nt<T>(x + row * ldx + c0);         // (the raw conv output is not read again before the backward pass: nontemporal)
     if (x2) in.v2 = ld16<T>(x2 + row * ldx2 + c0);
     if (res) in.vr = ld16<T>(res + row * ldr + c0);
     return in;
@@ -279,8 +279,11 @@ template <typename T> struct BnBwdReduceOp {
   struct In { Vec16<T> g, xv, yv; };
   __device__ In fetch(size_t row, int c0) const {
     In in;
-    in.g = ld16<T>(dy + row * lddy + c0);
-    in.xv = ld16<T>(x + row * ldx + c0);
+    // streaming loads (nontemporal): with the three BatchNorm passes reading their operands this way the step is 0.27 ms shorter
+    // (reduce 4.15 -> 4.6 TB/s; the apply pass no longer finds the reduce pass's lines in the memory-side cache and is 1 % slower,
+    // the sum wins) — A/B of all combinations in DESIGN.md section 4
+    in.g = ld16_nt<T>(dy + row * lddy + c0);
+    in.xv = ld16_nt<T>(x + row * ldx + c0);
     if (act && y) in.yv = ld16<T>(y + row * ldy + c0);
     return in;
   }
@@ -365,8 +368,8 @@ template <typename T> struct BnBwdApplyOp {
   struct In { Vec16<T> g, xv, yv, pv; };
   __device__ In fetch(size_t row, int c0) const {
     In in;
-    in.g = ld16<T>(dy + row * lddy + c0);
-    in.xv = ld16<T>(x + row * ldx + c0);
+    in.g = ld16_nt<T>(dy + row * lddy + c0);       // (last reads of both: nontemporal)
+    in.xv = ld16_nt<T>(x + row * ldx + c0);
     if (act && y) in.yv = ld16<T>(y + row * ldy + c0);
     if (dpost && post_acc) in.pv = ld16<T>(dpost + row * lddpost + c0);
     return in;

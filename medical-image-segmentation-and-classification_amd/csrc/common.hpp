@@ -123,6 +123,13 @@ __device__ __forceinline__ float row16_sum(float v) {
   return dpp_add<0x140>(v);
 }
 
+// streaming read: the line is not kept in the caches behind it (read-once operands of the HBM-bound passes)
+template <typename T> __device__ __forceinline__ Vec16<T> ld16_nt(const T* p) {
+  Vec16<T> r;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  *reinterpret_cast<u32x4*>(&r) = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+  return r;
+}
 template <typename T> __device__ __forceinline__ Vec16<T> ld16(const T* p) {
   Vec16<T> r;
   *reinterpret_cast<uint4*>(&r) = *reinterpret_cast<const uint4*>(p);

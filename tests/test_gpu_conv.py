@@ -345,6 +345,10 @@ def test_128_channel_ping_pong_variant_passes_the_same_cases():
     assert lib.mi355_conv2d_igemm_variant(32, 64, 256, 32, 64, 128, 3, 3, 1, 1, -1, 1, 0, code) == 6
     assert lib.mi355_conv2d_igemm_variant(32, 64, 128, 32, 64, 128, 3, 3, 1, 1, -1, 1, 0, code) == 2
     assert lib.mi355_conv2d_igemm_variant(32, 64, 256, 32, 64, 64, 3, 3, 1, 1, -1, 1, 0, code) == 2
+    # one 512-thread workgroup per CU: a batch whose grid does not fill the chip is served by the 4-wave kernel, and the statistics-
+    # row query (which knows N) follows the launcher — 32 x 32 x 512 -> 512: 32 images = 256 workgroups of 16 x 32 x 128, 16 images = 128
+    assert lib.mi355_conv2d_igemm_stat_rows(32, 32, 32, 512, 32, 32, 512, 3, 3, 1, 1, -1, 1, 0, code) == 32 * 2 * 1
+    assert lib.mi355_conv2d_igemm_stat_rows(16, 32, 32, 512, 32, 32, 512, 3, 3, 1, 1, -1, 1, 0, code) == 16 * 4 * 1
 
 
 def test_counted_vmcnt_matches_drained_build(tmp_path):

@@ -159,6 +159,9 @@ int mi355_bn_act(const void* x, int ldx, const float* scale, const float* shift,
  * partial sums of g and g*xhat per channel, g = dy * (y > 0 if act).  When `y` is NULL the ReLU mask
  * is recomputed as x*mscale[c]+mshift[c] > 0 (the forward's own coefficients), which saves reading
  * the activated tensor; `y` is required when a residual / second operand was added before the ReLU. */
+/* Partial rows mi355_bn_bwd_reduce can leave non-zero (= the workgroups it runs on, at most one per CU); rows from there up to
+ * mi355_rowreduce_blocks(M) are written as zeros, so mi355_bn_bwd_finalize may fold this many rows only. */
+int mi355_bn_bwd_reduce_rows(long long M);
 int mi355_bn_bwd_reduce(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,
                         const float* mean, const float* invstd, const float* mscale, const float* mshift,
                         float* partial, long long M, int C, int act, int dtype, mi355_stream_t s);

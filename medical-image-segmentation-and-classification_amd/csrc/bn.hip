@@ -302,6 +302,8 @@ template <typename T> struct BnBwdReduceOp {
   }
 };
 
+extern "C" int mi355_bn_bwd_reduce_rows(long long M) { return rowred_grid<BnBwdReduceOp<bf16_t>>(M); }
+
 extern "C" int mi355_bn_bwd_reduce(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,
                                    const float* mean, const float* invstd, const float* mscale, const float* mshift,
                                    float* partial, long long M, int C, int act, int dtype, mi355_stream_t s) {

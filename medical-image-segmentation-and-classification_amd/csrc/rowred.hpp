@@ -138,6 +138,20 @@ __global__ __launch_bounds__(256) void rowred_kernel(Op op, RowRedGeom g, float*
   }
 }
 
+// Workgroups a row reduction of op `Op` runs on = the partial rows it can leave non-zero (the rest, up to rowreduce_blocks(M), are
+// written as zeros): what a fold has to read.
+template <typename Op> static inline int rowred_grid(long long M) {
+  int nb = rowreduce_blocks(M);
+  static const int rr_wgs = getenv("MI355_RR_WGS") ? atoi(getenv("MI355_RR_WGS")) : 0;      // (A/B switch: one cap for every op)
+  if constexpr (has_fetch<Op>::value) {
+    int cap = 256;
+    if constexpr (has_max_wgs<Op>::value) cap = Op::MAX_WGS;      // (narrow rows: rowdot_bwd 256 / 512 / 1024 workgroups = 0.307 / 0.218 / 0.212 ms per step)
+    if (rr_wgs > 0) cap = rr_wgs;
+    nb = nb < cap ? nb : cap;
+  }
+  return nb;
+}
+
 template <typename T, typename Op>
 static inline int rowred_launch(const Op& op, long long M, int C, float* partial, hipStream_t s) {
   const int epc = 16 / (int)sizeof(T);
@@ -149,14 +163,7 @@ static inline int rowred_launch(const Op& op, long long M, int C, float* partial
   // flight per thread stream faster from ONE workgroup per CU (bn_bwd_apply 256^2 x 64: 1024 / 512 / 256 workgroups =
   // 4.97 / 5.03 / 5.35 TB/s); the rows of `partial` they do not produce are zero-filled.
   const int nb_rows = rowreduce_blocks(M);
-  int nb = nb_rows;
-  static const int rr_wgs = getenv("MI355_RR_WGS") ? atoi(getenv("MI355_RR_WGS")) : 0;      // (A/B switch: one cap for every op)
-  if constexpr (has_fetch<Op>::value) {
-    int cap = 256;
-    if constexpr (has_max_wgs<Op>::value) cap = Op::MAX_WGS;      // (narrow rows: rowdot_bwd 256 / 512 / 1024 workgroups = 0.307 / 0.218 / 0.212 ms per step)
-    if (rr_wgs > 0) cap = rr_wgs;
-    nb = nb < cap ? nb : cap;
-  }
+  const int nb = rowred_grid<Op>(M);
   RowRedGeom g = rowred_geom<T>(M, C, nb);
   g.nb_rows = nb_rows;
   const int cp = C / epc;

@@ -649,7 +649,10 @@ class Builder:
         if need_pg:
             gref, gbeta = self.pgrad(bn.weight)
             bref, _ = self.pgrad(bn.bias)
-        self.bwd.append(Launch("mi355_bn_bwd_finalize", part, nb, C, sums, gref if need_pg else None,
+        # (the reduction runs on at most 256 workgroups — rowred.hpp, ops that keep several rows in flight — and zero-fills the partial
+        # rows beyond its grid: the fold only has to read the rows that can be non-zero)
+        nb_fold = min(nb, lib.mi355_bn_bwd_reduce_rows(y.M))
+        self.bwd.append(Launch("mi355_bn_bwd_finalize", part, nb_fold, C, sums, gref if need_pg else None,
                                bref if need_pg else None, gbeta if need_pg else 0.0))
         dy = self.grad_of(y)
         dres = None

@@ -105,6 +105,14 @@ def test_classification_model(model, test_loader, device, model_name):
     m = calculate_classification_metrics(torch.cat(preds).cpu().numpy(), torch.cat(labels).cpu().numpy())
     print(f"\n{model_name} Test Results:\n{'-' * 60}")
     print(f"Accuracy:  {m['accuracy']:.2f}%\nPrecision: {m['precision']:.2f}%\nRecall:    {m['recall']:.2f}%\nF1 Score:  {m['f1']:.2f}%")
+    print("\nPer-Class Metrics:")
+    for i, c in enumerate(CLASSES[:len(m["f1_per_class"])]):   # (the reference indexes all of CLASSES, tester.py:282-296, and dies when a class is absent)
+        print(f"\n{c}:\n  Precision: {m['precision_per_class'][i]:.2f}%\n  Recall:    {m['recall_per_class'][i]:.2f}%\n"
+              f"  F1 Score:  {m['f1_per_class'][i]:.2f}%")
+    print("\nConfusion Matrix:")
+    print((" " * 25).join(f"{c:>12}" for c in CLASSES))      # the reference's header: names joined by 12 + 1 + 12 blanks (:299)
+    for i, row in enumerate(m["confusion_matrix"][:len(CLASSES)]):
+        print(f"{CLASSES[i]:<12}" + "".join(f"{v:>12}" for v in row))
     print(f"{'=' * 60}\n")
     return m
 

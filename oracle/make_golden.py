@@ -6,9 +6,20 @@ Run only in the build container (the reference never travels):
     PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
 
 The fixtures are data (inputs are regenerated from closed forms, expected outputs
-are stored); no reference source text is stored.  ``seaborn`` (used only by the
-reference's EDA plots, helpers.py:14,52-118) is absent from the image and is
-replaced by an empty module object so that ``utils.helpers`` imports.
+are stored); no reference source text is stored.  Third-party modules the image
+lacks and the functions under test never touch are replaced by EMPTY module
+objects so that the reference's modules import: ``seaborn`` (EDA plots only,
+helpers.py:14,52-118) for ``utils.helpers``; ``cv2``, ``albumentations``
+(+ ``.pytorch`` with a dummy ``ToTensorV2`` name), ``torchvision``
+(+ ``.transforms`` / ``.models``) for ``utils.tester``, ``utils.pipeline`` and
+``models.segmentation_models.ResnetUnet`` — of which only the metric functions,
+the two eval loops, the report writers (tester.py:92-312, 738-876), the two
+``Pipeline._predict_*`` methods (pipeline.py:324-357) and ``DecoderBlock``
+(ResnetUnet.py:17-27) are run: none of them reaches a stubbed module.  The
+torchvision ENCODERS (``ResNetUnet.__init__``, the hub models) and the
+Albumentations transforms do need the real libraries and stay unpinned.
+``utils.tester`` creates ``./results`` at import time (tester.py:38): the
+generator changes into a scratch directory first.
 """
 from __future__ import annotations
 
@@ -49,6 +60,38 @@ def _ref_helpers():
     sys.modules.setdefault("seaborn", types.ModuleType("seaborn"))
     import utils.helpers as H
     return H
+
+
+def _empty_module(name, **attrs):
+    if name not in sys.modules:
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+    return sys.modules[name]
+
+
+_SCRATCH = None
+
+
+def _ref_tester_pipeline():
+    """(utils.tester, utils.pipeline, DecoderBlock) of the reference, imported behind empty stand-in modules for the
+    third-party packages this image lacks (module docstring) from a scratch working directory."""
+    global _SCRATCH
+    import transformers  # noqa: F401  (models/classification_models/CLIP.py imports it; present in the image)
+    _empty_module("seaborn")
+    _empty_module("cv2")
+    a = _empty_module("albumentations")
+    a.pytorch = _empty_module("albumentations.pytorch", ToTensorV2=type("ToTensorV2", (), {}))
+    tv = _empty_module("torchvision")
+    tv.transforms = _empty_module("torchvision.transforms")
+    tv.models = _empty_module("torchvision.models")
+    if _SCRATCH is None:
+        _SCRATCH = tempfile.TemporaryDirectory()
+        os.chdir(_SCRATCH.name)
+    import utils.tester as T
+    import utils.pipeline as P
+    from models.segmentation_models.ResnetUnet import DecoderBlock
+    return T, P, DecoderBlock
 
 
 def _zero_dropout(m):
@@ -115,6 +158,7 @@ BLOCK_CASES = {   # tag -> (constructor args, input shapes); channel counts are 
     "Recurrent_block": ((32, 32, 5), [(2, 32, 8, 8)]),
     "RRCNN_block": ((32, 64, 2), [(2, 32, 8, 8)]),
     "BasicBlock_s2": ((32, 64, 2), [(2, 32, 8, 8)]),
+    "DecoderBlock": ((96, 32), [(2, 64, 4, 4), (2, 32, 8, 8)]),      # ResnetUnet.py:17-27: ConvT(64,64,2,2) -> cat skip -> basic_block(96,32)
 }
 
 
@@ -126,7 +170,8 @@ def block_fixtures(C):
     ctor = {"basic_block": C["basic_block"], "UpConv": C["UpConv"], "AttentionGate": C["AttentionGate"],
             "Recurrent_block": lambda a, b, t: C["Recurrent_block"](a, b, t=t),
             "RRCNN_block": lambda a, b, t: C["RRCNN_block"](a, b, t=t),
-            "BasicBlock_s2": lambda a, b, s: C["BasicBlock"](a, b, stride=s)}
+            "BasicBlock_s2": lambda a, b, s: C["BasicBlock"](a, b, stride=s),
+            "DecoderBlock": lambda a, b: _ref_tester_pipeline()[2](a, b)}
     for ti, (tag, (args, in_shapes)) in enumerate(BLOCK_CASES.items()):
         mod = ctor[tag](*args)
         mod.load_state_dict(nets.closed_form_fill(mod.state_dict(), salt=10.0 * ti))
@@ -149,32 +194,49 @@ def block_fixtures(C):
     print("blocks:", len(rec), "arrays")
 
 
-def train_traj_seg(C, H):
+def train_traj_seg(C, H, name="AttentionUNet", lr=1e-5):
     """Reference train() (helpers.py:231-412), segmentation branch, on a fixed synthetic
-    loader (shuffle off): parsed per-epoch log lines, best score, final checksums."""
+    loader (shuffle off): parsed per-epoch log lines, best score, final checksums.
+    The recurrent nets (R2AttU_Net.py:88-158, R2U_Net.py:50-111) run the same protocol at a 10x larger learning rate
+    — six optimiser steps that visibly move the shared-weight convolutions and accumulate 36 running-statistics updates per
+    recurrent BatchNorm — and additionally store a few FULL tensors of the final state."""
     from torch.utils.data import DataLoader, TensorDataset
-    hw, epochs, lr = 32, 3, 1e-5
+    hw, epochs = 32, 3
     xs, ys = zip(*[otrain.synthetic_batch(4, hw, seed=s) for s in (0, 1, 2)])
     tr = DataLoader(TensorDataset(torch.cat(xs[:2]), torch.cat(ys[:2])), batch_size=4, shuffle=False)
     va = DataLoader(TensorDataset(xs[2], ys[2]), batch_size=4, shuffle=False)
-    m = C["AttentionUNet"]()
-    m.load_state_dict(nets.closed_form_state("AttentionUNet"))
+    m = C[name]()
+    m.load_state_dict(nets.closed_form_state(name))
     buf = io.StringIO()
     with tempfile.TemporaryDirectory() as d, contextlib.redirect_stdout(buf):
-        best = H.train(m, tr, va, torch.device("cpu"), epochs, lr, "AttentionUNet", d, seg=True)
-        saved = torch.load(os.path.join(d, "AttentionUNet_best_loss.pt"))
+        best = H.train(m, tr, va, torch.device("cpu"), epochs, lr, name, d, seg=True)
+        saved = torch.load(os.path.join(d, f"{name}_best_loss.pt"))
     lines = re.findall(r"Ep(\d+): TrainLoss ([\d.]+) \| ValLoss ([\d.]+) \| IoU ([\d.]+)", buf.getvalue())
     sd = m.state_dict()
     names = list(sd.keys())
-    np.savez_compressed(
-        os.path.join(OUT, "train_traj_AttentionUNet.npz"),
+    rec = dict(
         hw=hw, epochs=epochs, lr=lr, best=float(best),
         log=np.array([[float(v) for v in l] for l in lines]),
         names=np.array(names),
         final_l2=np.array([float(sd[k].double().norm()) for k in names]),
         final_sum=np.array([float(sd[k].double().sum()) for k in names]),
         saved_l2=np.array([float(saved[k].double().norm()) for k in names]))
-    print("train_traj seg:", lines, "best", best)
+    if name != "AttentionUNet":
+        initial = nets.closed_form_state(name)
+        rec["moved_l2"] = np.array([float((sd[k].double() - initial[k].double()).norm()) for k in names])
+        for k in FULL_TENSORS[name]:
+            rec["full_" + k] = sd[k].numpy()
+        with torch.no_grad():                       # the final state's eval-mode logits on the validation batch
+            m.eval()
+            rec["final_val_logits"] = m(xs[2]).numpy()
+    np.savez_compressed(os.path.join(OUT, f"train_traj_{name}.npz"), **rec)
+    print(f"train_traj seg {name}:", lines, "best", best)
+
+
+FULL_TENSORS = {n: ("RRCNN1.RCNN.0.conv.0.weight", "RRCNN1.RCNN.0.conv.1.running_mean", "RRCNN1.RCNN.0.conv.1.running_var",
+                    "RRCNN3.RCNN.1.conv.1.running_var", "RRCNN5.RCNN.1.conv.1.running_mean", "up_RRCNN2.RCNN.1.conv.0.bias",
+                    "up_RRCNN2.RCNN.1.conv.1.weight", "up_RRCNN2.RCNN.1.conv.1.running_var", "conv_1x1.weight")
+                for n in ("R2AttU_Net", "R2U_Net")}
 
 
 def train_traj_cls(C, H):
@@ -217,6 +279,151 @@ def metric_fixture(H):
     np.savez_compressed(os.path.join(OUT, "metrics.npz"), pred=pred.numpy(), mask=mask.numpy(),
                         iou=H.iou(pred, mask), logits=logits.numpy(), y=y.numpy(), acc=np.array([c, n]))
     print("metrics: iou", H.iou(pred, mask), "acc", c, n)
+
+
+SEG_KEYS = ("iou", "dice", "pixel_accuracy", "precision", "recall", "f1")
+CLS_SCALARS = ("accuracy", "precision", "recall", "f1")
+CLS_ARRAYS = ("precision_per_class", "recall_per_class", "f1_per_class", "confusion_matrix")
+
+
+def _centred_resnet18(C, H, x):
+    """The reference's local ResNet18 + `add_dropout_to_fc` head at closed-form weights; the head bias is shifted by the
+    batch mean of the logits so that all three classes occur (closed-form weights put every image in class 0 otherwise).
+    Returns (model, shift): the shift is stored in the fixture as data."""
+    m = C["ResNet18"](num_classes=1000)
+    H.add_dropout_to_fc(m, p=0.0)
+    m.load_state_dict(nets.closed_form_state("ResNet18", head_dropout=True))
+    m.eval()
+    with torch.no_grad():
+        shift = m(x).mean(0)
+        m.fc[1].bias -= shift
+    return m, shift
+
+
+def tester_fixture(C, H):
+    """utils/tester.py run as it is (module docstring: empty stand-ins for cv2 / albumentations / torchvision):
+    calculate_iou / _dice / _pixel_accuracy / _segmentation_metrics (:92-193) on random and degenerate masks,
+    test_segmentation_model / test_classification_model (:197-312; return dicts AND printed text) over TensorDataset
+    loaders with the reference's own AttentionUNet / ResNet18 at closed-form weights, print_summary (:738-805) and
+    save_results_to_csv (:808-876) on the dictionaries those loops returned plus two hand-made rows."""
+    from torch.utils.data import DataLoader, TensorDataset
+    T, _, _ = _ref_tester_pipeline()
+    g = torch.Generator().manual_seed(4)
+    rnd = lambda *s: torch.rand(*s, generator=g)
+    one, zero = torch.ones(1, 12, 12), torch.zeros(1, 12, 12)
+    cases = {
+        "random": (rnd(1, 40, 40), (rnd(1, 40, 40) > 0.6).float()),
+        "random_soft_target": (rnd(1, 24, 24), rnd(1, 24, 24)),             # targets are thresholded too (:105)
+        "empty_prediction": (zero + 0.2, (rnd(1, 12, 12) > 0.5).float()),
+        "empty_target": (rnd(1, 12, 12), zero),
+        "both_empty": (zero + 0.1, zero),
+        "both_full": (one * 0.9, one),
+        "at_threshold": (zero + 0.5, one),                                  # 0.5 is NOT above the threshold
+        "perfect": ((rnd(1, 12, 12) > 0.5).float(),) * 2,
+        "batch_of_images": (rnd(3, 1, 16, 16), (rnd(3, 1, 16, 16) > 0.5).float()),   # the functions sum over whatever they get
+    }
+    rec = {"seg/names": np.array(list(cases)), "seg_keys": np.array(SEG_KEYS)}
+    for tag, (p, t) in cases.items():
+        t = t.clone()
+        rec[f"seg/{tag}/pred"], rec[f"seg/{tag}/target"] = p.numpy(), t.numpy()
+        rec[f"seg/{tag}/iou"] = T.calculate_iou(p, t)
+        rec[f"seg/{tag}/dice"] = T.calculate_dice(p, t)
+        rec[f"seg/{tag}/pixel_accuracy"] = T.calculate_pixel_accuracy(p, t)
+        m = T.calculate_segmentation_metrics(p, t)
+        assert tuple(m) == SEG_KEYS
+        rec[f"seg/{tag}/metrics"] = np.array([m[k] for k in SEG_KEYS])
+    m7 = T.calculate_segmentation_metrics(cases["random"][0], cases["random"][1], threshold=0.7)
+    rec["seg/random/metrics_t0.7"] = np.array([m7[k] for k in SEG_KEYS])
+
+    # --- eval loops -------------------------------------------------------------------------------------------------
+    seg = C["AttentionUNet"]()
+    seg.load_state_dict(nets.closed_form_state("AttentionUNet"))
+    xs, ms = zip(*[otrain.synthetic_batch(3, 32, seed=s) for s in (5, 6)])
+    dl = DataLoader(TensorDataset(torch.cat(xs), torch.cat(ms)), batch_size=3)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+        seg_res = T.test_segmentation_model(seg, dl, torch.device("cpu"), "AttentionUNet")
+    rec["segloop/metrics"] = np.array([seg_res[k] for k in SEG_KEYS])
+    rec["segloop/stdout"] = np.array(buf.getvalue())
+
+    x, y = otrain.synthetic_batch(12, 64, seed=20, classes=3)
+    cls, shift = _centred_resnet18(C, H, x)
+    dl = DataLoader(TensorDataset(x, y), batch_size=5)                      # ragged last batch
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+        cls_res = T.test_classification_model(cls, dl, torch.device("cpu"), "ResNet18")
+    rec["clsloop/bias_shift"] = shift.numpy()
+    for k in CLS_SCALARS:
+        rec[f"clsloop/{k}"] = cls_res[k]
+    for k in CLS_ARRAYS:
+        rec[f"clsloop/{k}"] = np.asarray(cls_res[k])
+    rec["clsloop/stdout"] = np.array(buf.getvalue())
+    with torch.no_grad():
+        z = cls(x)
+    top = z.sort(1, descending=True).values
+    rec["clsloop/logit_margin"] = (top[:, 0] - top[:, 1]).numpy()
+    rec["clsloop/pred"] = z.argmax(1).numpy()
+
+    # --- reports ----------------------------------------------------------------------------------------------------
+    results = {"ResNet18": cls_res,
+               "VGG16": {"accuracy": 93.0, "precision": 92.0, "recall": 93.0, "f1": 92.5},
+               "AttentionUNet": seg_res,
+               "R2Unet": {"iou": 79.0, "dice": 87.25, "pixel_accuracy": 96.5, "precision": 88.0, "recall": 86.5, "f1": 87.24}}
+    def said(fn, *a):
+        b = io.StringIO()
+        with contextlib.redirect_stdout(b):
+            fn(*a)
+        return np.array(b.getvalue())
+    rec["report/summary"] = said(T.print_summary, results)
+    rec["report/summary_empty"] = said(T.print_summary, {})
+    rec["report/summary_seg_only"] = said(T.print_summary, {"AttentionUNet": seg_res})
+    with tempfile.TemporaryDirectory() as d:
+        c, s_ = os.path.join(d, "c.csv"), os.path.join(d, "s.csv")
+        rec["report/csv_stdout"] = np.array(str(said(T.save_results_to_csv, results, c, s_)).replace(d, "<dir>"))
+        rec["report/csv_cls"], rec["report/csv_seg"] = np.array(open(c).read()), np.array(open(s_).read())
+        rec["report/csv_stdout_seg_only"] = np.array(
+            str(said(T.save_results_to_csv, {"AttentionUNet": seg_res}, c, s_)).replace(d, "<dir>"))
+        rec["report/csv_stdout_empty"] = said(T.save_results_to_csv, {}, c, s_)
+    np.savez_compressed(os.path.join(OUT, "tester.npz"), **rec)
+    print("tester:", len(cases), "metric cases; seg loop", seg_res, "; cls loop acc", cls_res["accuracy"], "pred", rec["clsloop/pred"])
+
+
+def pipeline_fixture(C, H):
+    """utils/pipeline.py:324-357 `Pipeline._predict_classification` / `_predict_segmentation` run as they are, on a
+    Pipeline object whose two models are set by hand (the reference's own ResNet18 / AttentionUNet classes at closed-form
+    weights; `_load_models` would fetch from the hub): per image the class string, the confidence in percent and the
+    uint8 mask.  Both calls are recorded for EVERY image; `process_image` (:359-418) only segments the "COVID" ones."""
+    _, P, _ = _ref_tester_pipeline()
+    x, _ = otrain.synthetic_batch(12, 64, seed=21, classes=3)
+    cls, shift = _centred_resnet18(C, H, x)
+    seg = C["AttentionUNet"]()
+    seg.load_state_dict(nets.closed_form_state("AttentionUNet"))
+    seg.eval()
+    pipe = P.Pipeline.__new__(P.Pipeline)
+    pipe.classification_model, pipe.segmentation_model = cls, seg
+    preds, confs, masks = [], [], []
+    for i in range(x.shape[0]):
+        p, c = pipe._predict_classification(x[i:i + 1])
+        preds.append(P.CLASSES.index(p)); confs.append(c)
+        mk = pipe._predict_segmentation(x[i:i + 1])
+        assert mk.dtype == np.uint8 and mk.shape == (64, 64) and set(np.unique(mk)) <= {0, 255}
+        masks.append(mk)
+    with torch.no_grad():
+        z = cls(x)
+        zs = seg(x)
+    top = z.sort(1, descending=True).values
+    pipe.segmentation_model = None
+    assert pipe._predict_segmentation(x[:1]) is None
+    pipe.segmentation_model = P.PlaceholderModel()
+    assert pipe._predict_segmentation(x[:1]) is None
+    pipe.classification_model = None
+    none_cls = pipe._predict_classification(x[:1])
+    np.savez_compressed(
+        os.path.join(OUT, "pipeline.npz"), classes=np.array(P.CLASSES), bias_shift=shift.numpy(), pred=np.array(preds),
+        confidence=np.array(confs), masks=np.packbits(np.stack(masks) == 255, axis=-1), hw=64,
+        logit_margin=(top[:, 0] - top[:, 1]).numpy(), seg_logit_near_zero=(zs.abs() < 1e-3).sum(dim=(1, 2, 3)).numpy(),
+        no_cls_model=np.array([str(none_cls[0]), str(none_cls[1])]))
+    print("pipeline: pred", preds, "conf", [round(c, 2) for c in confs], "mask px", [int((m > 0).sum()) for m in masks])
 
 
 def cls_metric_fixture():
@@ -309,6 +516,8 @@ def main(only=()):
     jobs = {
         "blocks": lambda: block_fixtures(C),
         "metrics": lambda: metric_fixture(H),
+        "tester": lambda: tester_fixture(C, H),
+        "pipeline": lambda: pipeline_fixture(C, H),
         "cls_metrics": cls_metric_fixture,
         "png": png_fixture,
         "AttentionUNet": lambda: model_fixture("AttentionUNet", C["AttentionUNet"], 64, True),
@@ -319,6 +528,8 @@ def main(only=()):
         "VGG16": lambda: model_fixture("VGG16", lambda: C["VGG16"](num_classes=1000), 32, False, head_dropout=True, H=H),
         "VGG19": lambda: model_fixture("VGG19", lambda: C["VGG19"](num_classes=1000), 32, False, head_dropout=True, H=H),
         "train_traj_seg": lambda: train_traj_seg(C, H),
+        "train_traj_R2AttU_Net": lambda: train_traj_seg(C, H, "R2AttU_Net", lr=1e-4),
+        "train_traj_R2U_Net": lambda: train_traj_seg(C, H, "R2U_Net", lr=1e-4),
         "train_traj_cls": lambda: train_traj_cls(C, H),
     }
     for k in (only or jobs):

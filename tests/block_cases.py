@@ -17,6 +17,7 @@ CASES = {   # tag -> (constructor args, input shapes) — keep in sync with orac
     "Recurrent_block": ((32, 32, 5), [(2, 32, 8, 8)]),
     "RRCNN_block": ((32, 64, 2), [(2, 32, 8, 8)]),
     "BasicBlock_s2": ((32, 64, 2), [(2, 32, 8, 8)]),
+    "DecoderBlock": ((96, 32), [(2, 64, 4, 4), (2, 32, 8, 8)]),      # ResnetUnet.py:17-27 (imported behind empty torchvision stand-ins)
 }
 ORDER = list(CASES)
 

@@ -27,6 +27,11 @@ def _make(tag):
         blk, low = B.Recurrent_block(args[0], args[1], t=args[2]), lambda g, b, xs: b.lower(g, xs[0])
     elif tag == "RRCNN_block":
         blk, low = B.RRCNN_block(args[0], args[1], t=args[2]), lambda g, b, xs: b.lower(g, xs[0])
+    elif tag == "DecoderBlock":
+        from models.segmentation_models.ResnetUnet import DecoderBlock
+        # the block net has ONE input: `down` (4 x 4) rides in as its nearest x2 up-sampling next to `skip` (8 x 8) and is recovered
+        # exactly by a 2 x 2 max-pool of four equal values; its gradient lands on the first element of every 2 x 2 block
+        blk, low = DecoderBlock(*args), lambda g, b, xs: b.lower(g, g.maxpool(xs[0], 2, 2, 0), xs[1])
     else:
         blk, low = BasicBlock(args[0], args[1], stride=args[2]), lambda g, b, xs: b.lower(g, xs[0])
     chans = [s[1] for s in bc.CASES[tag][1]]
@@ -48,6 +53,13 @@ def _make(tag):
     return BlockNet()
 
 
+def _net_input(tag):
+    ins = bc.inputs(tag)
+    if tag == "DecoderBlock":
+        ins = [ins[0].repeat_interleave(2, 2).repeat_interleave(2, 3), ins[1]]
+    return torch.cat(ins, 1)
+
+
 @pytest.mark.parametrize("tag", bc.ORDER)
 def test_block_fp32_matches_reference(tag):
     z = bc.load()
@@ -55,7 +67,7 @@ def test_block_fp32_matches_reference(tag):
     net.compute_dtype = torch.float32
     net = net.to(DEV).train()
     ins = bc.inputs(tag)
-    x = torch.cat(ins, 1).to(DEV)
+    x = _net_input(tag).to(DEV)
     out = net(x)
     ref = z[tag + "/out"]
     w = bc.out_weight(tag, ref.shape)
@@ -67,7 +79,10 @@ def test_block_fp32_matches_reference(tag):
     o = 0
     for i, t in enumerate(ins):
         r = z[f"{tag}/din{i}"]
-        got = din[:, o:o + t.shape[1]].numpy()
+        got = din[:, o:o + t.shape[1]]
+        if got.shape[2:] != t.shape[2:]:            # DecoderBlock's `down`: fold the 2 x 2 blocks of its up-sampled carrier
+            got = got.reshape(t.shape[0], t.shape[1], t.shape[2], 2, t.shape[3], 2).sum((3, 5))
+        got = got.numpy()
         o += t.shape[1]
         assert np.abs(got - r).max() < tol * np.abs(r).max(), (i, np.abs(got - r).max(), np.abs(r).max())
     # conv biases in front of a train-mode BN have a mathematically zero gradient (pure round-off in
@@ -88,7 +103,7 @@ def test_block_bf16_close_to_reference(tag):
     net = _make(tag)
     net.compute_dtype = torch.bfloat16
     net = net.to(DEV).train()
-    x = torch.cat(bc.inputs(tag), 1).to(DEV)
+    x = _net_input(tag).to(DEV)
     with torch.no_grad():
         out = net(x)
     ref = z[tag + "/out"]

@@ -294,6 +294,45 @@ def test_tester_functions_match_oracle_metrics(capsys):
     assert abs(cm["accuracy"] - 100 * 5 / 7) < 1e-9 and cm["confusion_matrix"].sum() == 7
 
 
+def test_tester_eval_loops_match_the_reference_tester(capsys):
+    """utils.tester.test_segmentation_model / test_classification_model on the GPU against the dictionaries AND the printed text
+    the REFERENCE's loops (tester.py:197-312, run by oracle/make_golden.py on its own AttentionUNet / ResNet18 at the same
+    closed-form weights and loaders) returned; the metric helpers on device tensors against the reference's values."""
+    from torch.utils.data import DataLoader, TensorDataset
+    from utils import tester
+    z = np.load(os.path.join(G, "tester.npz"), allow_pickle=False)
+    keys = [str(k) for k in z["seg_keys"]]
+    for tag in [str(s_) for s_ in z["seg/names"]]:
+        p, t = torch.from_numpy(z[f"seg/{tag}/pred"]).to(DEV), torch.from_numpy(z[f"seg/{tag}/target"]).to(DEV)
+        got = tester.calculate_segmentation_metrics(p, t)
+        assert np.allclose([got[k] for k in keys], z[f"seg/{tag}/metrics"], rtol=2e-5, atol=2e-5), tag
+        assert abs(tester.calculate_dice(p, t) - float(z[f"seg/{tag}/dice"])) < 1e-6
+    m, _, _ = _build("AttentionUNet", torch.float32)
+    xs, ms = zip(*[otrain.synthetic_batch(3, 32, seed=s_) for s_ in (5, 6)])
+    dl = DataLoader(TensorDataset(torch.cat(xs), torch.cat(ms)), batch_size=3)
+    avg = tester.test_segmentation_model(m, dl, torch.device(DEV), "AttentionUNet")
+    out = capsys.readouterr().out
+    assert list(avg) == keys
+    # percent; one pixel of the 6 x 1024 is 0.016 and a handful sit at p = 0.5 +- 1e-4
+    assert np.abs(np.array([avg[k] for k in keys]) - z["segloop/metrics"]).max() < 0.2, (avg, z["segloop/metrics"])
+    ref_text = str(z["segloop/stdout"])
+    strip = lambda txt: [ln.split(":")[0] if "%" in ln else ln for ln in txt.splitlines()]      # same lines, numbers aside
+    assert strip(out) == strip(ref_text)
+
+    cm, _, _ = _build("ResNet18", torch.float32)
+    with torch.no_grad():
+        cm.fc[1].bias -= torch.from_numpy(z["clsloop/bias_shift"]).to(DEV)
+    x, y = otrain.synthetic_batch(12, 64, seed=20, classes=3)
+    assert z["clsloop/logit_margin"].min() > 0.05                      # the fixture's decisions are clear of fp32 noise
+    res = tester.test_classification_model(cm, DataLoader(TensorDataset(x, y), batch_size=5), torch.device(DEV), "ResNet18")
+    out = capsys.readouterr().out
+    for k in ("accuracy", "precision", "recall", "f1"):
+        assert abs(res[k] - float(z[f"clsloop/{k}"])) < 1e-9, k
+    for k in ("precision_per_class", "recall_per_class", "f1_per_class", "confusion_matrix"):
+        assert np.allclose(res[k], z[f"clsloop/{k}"], atol=1e-9), k
+    assert out == str(z["clsloop/stdout"])                              # identical decisions => identical text
+
+
 def test_test_all_models_walks_the_weight_directories(tmp_path, capsys):
     """utils.tester.test_all_models (tester.py:513-735): evaluates the checkpoints that exist under the reference's file
     names, skips the missing ones with the reference's warning, takes the dataset-not-found branch without a loader, and

@@ -178,3 +178,36 @@ def test_pipeline_from_png_files(tmp_path):
         assert abs(c1 - c2) <= 1e-2 * c2 and (m1 is None) == (m2 is None)
         if m1 is not None:
             assert float((m1 != m2).float().mean()) <= 5e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_joint_pipeline_matches_reference_pipeline_fixture(dtype):
+    """The REFERENCE's `Pipeline._predict_classification` / `_predict_segmentation` (pipeline.py:324-357, run by
+    oracle/make_golden.py with its own ResNet18 / AttentionUNet set by hand) against the batched GPU path on the same weights
+    and images: class, confidence in percent, and the uint8 mask of every image the decision of `process_image` segments."""
+    import os
+    import numpy as np
+    from oracle import train as otrain
+    from utils.pipeline import JointPipeline
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "pipeline.npz"), allow_pickle=False)
+    cls_sd = nets.closed_form_state("ResNet18", head_dropout=True)
+    cls_sd["fc.1.bias"] = cls_sd["fc.1.bias"] - torch.from_numpy(z["bias_shift"])
+    cm, sm = _models(dtype, cls_sd, nets.closed_form_state("AttentionUNet"), "ResNet18")
+    x, _ = otrain.synthetic_batch(12, 64, seed=21, classes=3)
+    got = JointPipeline(cm, sm, device=DEV, bucket=4).process_batch(x)
+    masks = np.unpackbits(z["masks"], axis=-1)[..., :int(z["hw"])].astype(np.uint8) * 255
+    classes = [str(c) for c in z["classes"]]
+    sure = z["logit_margin"] > (0.0 if dtype == torch.float32 else 1.0)
+    assert int(sure.sum()) >= 9
+    n_masks = 0
+    for i, (p, c, m) in enumerate(got):
+        if not sure[i]:
+            continue
+        assert p == classes[int(z["pred"][i])], i
+        assert abs(c - float(z["confidence"][i])) <= (1e-3 if dtype == torch.float32 else 0.25) * float(z["confidence"][i])
+        assert (m is not None) == (p == "COVID")
+        if m is not None:
+            bad = int((m.numpy() != masks[i]).sum())
+            assert bad <= (int(z["seg_logit_near_zero"][i]) + 2 if dtype == torch.float32 else 0.02 * masks[i].size), (i, bad)
+            n_masks += 1
+    assert n_masks >= 2

@@ -13,6 +13,7 @@ ORACLE = {
     "Recurrent_block": lambda sd, ins: nets.recurrent(sd, "", ins[0], 5, True),
     "RRCNN_block": lambda sd, ins: nets.rrcnn(sd, "", ins[0], 2, True),
     "BasicBlock_s2": lambda sd, ins: nets._basic_block(sd, "", ins[0], 2, True),
+    "DecoderBlock": lambda sd, ins: nets._decoder_block(sd, "", ins[0], ins[1], True),
 }
 SHAPES = {   # state_dict layouts of the reference blocks, via the oracle's spec helpers
     "basic_block": lambda s: nets._spec_double_conv(s, "", 32, 64),
@@ -22,6 +23,7 @@ SHAPES = {   # state_dict layouts of the reference blocks, via the oracle's spec
     "RRCNN_block": lambda s: nets._spec_rrcnn(s, "", 32, 64),
     "BasicBlock_s2": lambda s: (s.conv(".conv1", 32, 64, 3, False), s.conv(".conv2", 64, 64, 3, False), s.bn(".bn1", 64),
                                 s.bn(".bn2", 64), s.conv(".identity.0", 32, 64, 1, False), s.bn(".identity.1", 64)),
+    "DecoderBlock": lambda s: (nets._spec_double_conv(s, ".basic_block", 96, 32), s.convT(".up_sample", 64, 64, 2)),   # registration order of ResnetUnet.py:20-21
 }
 
 

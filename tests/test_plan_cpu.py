@@ -113,31 +113,31 @@ def test_no_cpu_fallback():
 
 
 def test_tester_reports_match_the_reference_text(tmp_path, capsys):
-    """utils.tester.print_summary / save_results_to_csv (tester.py:738-876): table text, best-model lines, the family split by
-    model name and the columns that are dropped from the classification CSV."""
+    """utils.tester.print_summary / save_results_to_csv against the text and the CSV files the REFERENCE's functions
+    (tester.py:738-876, run by oracle/make_golden.py) produced for the same result dictionaries: both tables, the best-model
+    lines, the family split by model name, the columns dropped from the classification CSV, pandas' float formatting, and the
+    empty / one-family branches."""
+    import os
     import numpy as np
     from utils import tester
-    res = {"ResNet18": {"accuracy": 91.256, "precision": 90.5, "recall": 91.0, "f1": 90.749, "precision_per_class": np.zeros(3),
-                        "recall_per_class": np.zeros(3), "f1_per_class": np.zeros(3), "confusion_matrix": np.eye(3)},
-           "VGG16": {"accuracy": 93.0, "precision": 92.0, "recall": 93.0, "f1": 92.5},
-           "AttentionUNet": {"iou": 80.123, "dice": 88.5, "pixel_accuracy": 97.0, "precision": 89.0, "recall": 88.0, "f1": 88.5},
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "tester.npz"), allow_pickle=False)
+    cls = {k: float(z[f"clsloop/{k}"]) for k in ("accuracy", "precision", "recall", "f1")}
+    cls.update({k: z[f"clsloop/{k}"] for k in ("precision_per_class", "recall_per_class", "f1_per_class", "confusion_matrix")})
+    seg = dict(zip([str(k) for k in z["seg_keys"]], [float(v) for v in z["segloop/metrics"]]))
+    res = {"ResNet18": cls, "VGG16": {"accuracy": 93.0, "precision": 92.0, "recall": 93.0, "f1": 92.5}, "AttentionUNet": seg,
            "R2Unet": {"iou": 79.0, "dice": 87.25, "pixel_accuracy": 96.5, "precision": 88.0, "recall": 86.5, "f1": 87.24}}
-    tester.print_summary(res)
-    out = capsys.readouterr().out
-    assert " " * 25 + "TEST RESULTS SUMMARY" in out
-    assert f"{'ResNet18':<20} {91.256:>10.2f}% {90.5:>10.2f}% {91.0:>10.2f}% {90.749:>10.2f}%" in out
-    assert "Best Classification Model: VGG16 (Accuracy: 93.00%)" in out
-    assert f"{'R2Unet':<20} {79.0:>8.2f}% {87.25:>8.2f}% {88.0:>10.2f}% {86.5:>10.2f}% {87.24:>10.2f}%" in out
-    assert "Best Segmentation Model: AttentionUNet (Dice: 88.50%)" in out
-    tester.print_summary({})
-    assert "No test results to display" in capsys.readouterr().out
-    c, s_ = tmp_path / "cls.csv", tmp_path / "seg.csv"
-    tester.save_results_to_csv(res, str(c), str(s_))
-    assert c.read_text() == "Model,accuracy,precision,recall,f1\nResNet18,91.256,90.5,91.0,90.749\nVGG16,93.0,92.0,93.0,92.5\n"
-    assert s_.read_text() == ("Model,iou,dice,pixel_accuracy,precision,recall,f1\nAttentionUNet,80.123,88.5,97.0,89.0,88.0,88.5\n"
-                              "R2Unet,79.0,87.25,96.5,88.0,86.5,87.24\n")
-    tester.save_results_to_csv({"AttentionUNet": res["AttentionUNet"]}, str(c), str(s_))
-    assert "No classification results to save" in capsys.readouterr().out
+
+    def said(fn, *a):
+        fn(*a)
+        return capsys.readouterr().out.replace(str(tmp_path), "<dir>")
+    assert said(tester.print_summary, res) == str(z["report/summary"])
+    assert said(tester.print_summary, {}) == str(z["report/summary_empty"])
+    assert said(tester.print_summary, {"AttentionUNet": seg}) == str(z["report/summary_seg_only"])
+    c, s_ = tmp_path / "c.csv", tmp_path / "s.csv"
+    assert said(tester.save_results_to_csv, res, str(c), str(s_)) == str(z["report/csv_stdout"])
+    assert c.read_text() == str(z["report/csv_cls"]) and s_.read_text() == str(z["report/csv_seg"])
+    assert said(tester.save_results_to_csv, {"AttentionUNet": seg}, str(c), str(s_)) == str(z["report/csv_stdout_seg_only"])
+    assert said(tester.save_results_to_csv, {}, str(c), str(s_)) == str(z["report/csv_stdout_empty"])
 
 
 def test_recurrent_convs_get_one_weight_gradient_launch(monkeypatch):

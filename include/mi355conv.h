@@ -77,7 +77,7 @@ int mi355_pack_conv_weights_batched(const int64_t* table, int n, int fields /* =
  * bit 1 applies max(0, .) to conv + bias first (nn.ReLU fused into the epilogue: VGG.py:9-41, and eval-mode
  * Conv -> BN -> ReLU with the BN folded into weights and bias), bit 2 sums every 2x2 group of output pixels into a
  * half-resolution `out` [N][Ho/2][Wo/2] (the gradient of the nearest x2 up-sampling that the forward conv folds into
- * its gather, AttentionUNet.py:19; halo kernels only: mi355_conv2d_igemm_variant(...) in {2, 3, 5, 6}).
+ * its gather, AttentionUNet.py:19; halo kernels only: mi355_conv2d_igemm_variant(...) in {2, 3, 5, 6, 7}).
  * bf16 / fp16 dispatch: 3x3/s1/p1 with Co % 64 == 0 on images divisible by an 8x32 or 16x16 tile ->
  * conv3x3_halo_rw_kernel (halo patch in LDS by LDS-DMA, patch-row register window); 1x1/s1 with (Ci, Co) among
  * 32/64/128-channel pairs (the attention-gate projections, AttentionUNet.py:33-45) -> conv1x1_stream_kernel (weights in
@@ -92,9 +92,14 @@ int mi355_conv2d_igemm(const void* in, const void* wk, const float* bias, void* 
  * 4 streaming pointwise kernel, 5 / 6 the 512-thread ping-pong halo kernels with 64 / 128 output channels per workgroup
  * (5: MI355_HALO_PP=1 only; 6: 3x3/s1/p1, Co % 128 == 0, Ci % 64 == 0 and Ci >= 256, image divisible by 16 x 32 — one workgroup
  * per CU, so the launcher falls back to variant 2 for a batch whose grid would leave more than a fifth of the last round of
- * workgroups empty; mi355_conv2d_igemm_stat_rows, which knows N, follows the launcher). */
+ * workgroups empty; mi355_conv2d_igemm_stat_rows, which knows N, follows the launcher); 7 the weight-stationary persistent
+ * kernel (3x3/s1/p1, Ci == 64, Co % 64 == 0, image divisible by 8 x 32: the 64-channel layers of every U-Net level,
+ * AttentionUNet.py:62-63,82, R2AttU_Net.py:36-39; the launcher falls back to variant 2 below two tiles per workgroup). */
 int mi355_conv2d_igemm_variant(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int mul, int kmul, int off,
                                int div, int up, int dtype);
+/* ... and the variant the launcher actually runs for a batch of N images (the batch-dependent fall-backs applied). */
+int mi355_conv2d_igemm_variant_n(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int mul, int kmul,
+                                 int off, int div, int up, int dtype);
 /* Fused BatchNorm statistics: when `stats` != NULL the epilogue also writes, per M tile b of the kernel
  * (per WORKGROUP for the streaming pointwise kernel) it dispatches to, stats[(b*2+0)*Co + c] = sum and stats[(b*2+1)*Co + c] = sum of squares of the
  * (rounded) outputs — the same partial layout mi355_bn_finalize consumes.  The number of tile rows is

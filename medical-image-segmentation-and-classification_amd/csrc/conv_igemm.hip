@@ -507,6 +507,7 @@ static int launch_dma(const ConvArgs& a, hipStream_t s) {
 #include "conv3x3_halo.hpp"
 #include "conv3x3_halo_pp.hpp"
 #include "conv3x3_halo_pp128.hpp"
+#include "conv3x3_ws64.hpp"
 #include "conv1x1_stream.hpp"
 
 template <typename T, int BN, int BK>
@@ -524,7 +525,7 @@ static int launch_bn(const ConvArgs& a, hipStream_t s) {
   return launch<T, 32, BK>(a, s);
 }
 
-enum IgemmVariant { IG_GENERIC = 0, IG_DMA, IG_HALO_8x32, IG_HALO_16x16, IG_STREAM1x1, IG_HALO_PP, IG_HALO_PP128 };
+enum IgemmVariant { IG_GENERIC = 0, IG_DMA, IG_HALO_8x32, IG_HALO_16x16, IG_STREAM1x1, IG_HALO_PP, IG_HALO_PP128, IG_WS64 };
 
 // ONE place that decides which kernel serves a shape (also used by the statistics-row query).
 static IgemmVariant pick_variant(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int mul, int kmul, int off,
@@ -549,6 +550,9 @@ static IgemmVariant pick_variant(int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
     static const int pp128 = getenv("MI355_HALO_PP128") ? atoi(getenv("MI355_HALO_PP128")) : 1;
     static const int pp128_min_ci = getenv("MI355_HALO_PP128_MINCI") ? atoi(getenv("MI355_HALO_PP128_MINCI")) : 256;
     if (pp128 && Co % 128 == 0 && Ci % 64 == 0 && Ci >= pp128_min_ci && Wo % 32 == 0 && Ho % 16 == 0) return IG_HALO_PP128;
+    // Ci = 64: weights stationary in registers, persistent workgroups (conv3x3_ws64.hpp); MI355_WS64=0 switches it off (A/B)
+    static const int ws64 = getenv("MI355_WS64") ? atoi(getenv("MI355_WS64")) : 1;
+    if (ws64 && ws64_shape(1, Hi, Wi, Ci, Ho, Wo, Co)) return IG_WS64;
     if (Wo % 32 == 0 && Ho % 8 == 0) return IG_HALO_8x32;
     if (Wo % 16 == 0 && Ho % 16 == 0) return IG_HALO_16x16;
   }
@@ -562,13 +566,25 @@ static IgemmVariant pick_variant(int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
 // The 128-channel ping-pong kernel runs ONE 512-thread workgroup per CU: a grid that leaves a quarter of the last round of
 // workgroups empty (or does not fill the chip once: 32 images of 32 x 32 x 256 channels = 128 workgroups) is served by the
 // 4-wave kernel, whose grid is four times finer.  Batch-dependent, hence not part of the shape-level variant query.
-static IgemmVariant resolve_variant(IgemmVariant v, int N, int Ho, int Wo, int Co) {
-  if (v != IG_HALO_PP128) return v;
+static int device_cus() {
   static const int cus = [] {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
     return n;
   }();
+  return cus;
+}
+static IgemmVariant resolve_variant(IgemmVariant v, int N, int Ho, int Wo, int Co) {
+  // the weight-stationary kernel is persistent (2 workgroups per CU): it wants at least two tiles per workgroup to amortise
+  // its weight load, else the 4-wave kernel with its four-times finer grid
+  // (MI355_WS64_MIN_TILES lowers the threshold: the parity tests run it on small shapes, one tile per workgroup included)
+  if (v == IG_WS64) {
+    static const long long min_tiles = getenv("MI355_WS64_MIN_TILES") ? atoll(getenv("MI355_WS64_MIN_TILES")) : 4ll * device_cus();
+    const long long S = (long long)N * (Ho / 8) * (Wo / 32);
+    return S >= 8 && S * (Co / 64) >= min_tiles ? IG_WS64 : IG_HALO_8x32;
+  }
+  if (v != IG_HALO_PP128) return v;
+  const int cus = device_cus();
   const long long grid = (long long)N * (Ho / 16) * (Wo / 32) * (Co / 128);
   const long long rounds = (grid + cus - 1) / cus;
   return grid * 5 >= rounds * cus * 4 ? IG_HALO_PP128 : IG_HALO_8x32;          // >= 80 % of the last round filled
@@ -579,11 +595,17 @@ extern "C" int mi355_conv2d_igemm_variant(int Hi, int Wi, int Ci, int Ho, int Wo
   return (int)pick_variant(Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up, dtype);
 }
 
+extern "C" int mi355_conv2d_igemm_variant_n(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int mul, int kmul,
+                                            int off, int div, int up, int dtype) {
+  return (int)resolve_variant(pick_variant(Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up, dtype), N, Ho, Wo, Co);
+}
+
 extern "C" int mi355_conv2d_igemm_stat_rows(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int mul,
                                             int kmul, int off, int div, int up, int dtype) {
   switch (resolve_variant(pick_variant(Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up, dtype), N, Ho, Wo, Co)) {
     case IG_HALO_PP:
     case IG_HALO_PP128: return N * (Ho / 16) * (Wo / 32);
+    case IG_WS64:
     case IG_HALO_8x32: return N * (Ho / 8) * (Wo / 32);
     case IG_HALO_16x16: return N * (Ho / 16) * (Wo / 16);
     case IG_DMA: return ceil_div((long long)N * Ho * Wo, 128);
@@ -621,7 +643,7 @@ extern "C" int mi355_conv2d_igemm(const void* in, const void* wk, const float* b
   a.accumulate = accumulate & 1;
   a.relu = (accumulate >> 1) & 1;
   a.pool2 = (accumulate >> 2) & 1;
-  MI355_CHECK_ARG(!a.pool2 || ((v == IG_HALO_8x32 || v == IG_HALO_16x16 || v == IG_HALO_PP || v == IG_HALO_PP128) && !stats),
+  MI355_CHECK_ARG(!a.pool2 || ((v == IG_HALO_8x32 || v == IG_HALO_16x16 || v == IG_HALO_PP || v == IG_HALO_PP128 || v == IG_WS64) && !stats),
                   "conv2d_igemm: the 2x2-sum epilogue exists for the halo kernel only (mi355_conv2d_igemm_variant >= 2)");
   a.stats = stats;
   a.M = N * Ho * Wo;
@@ -637,6 +659,7 @@ extern "C" int mi355_conv2d_igemm(const void* in, const void* wk, const float* b
       switch (v) {
         case IG_HALO_PP: return launch_halo_pp<T>(a, st);
         case IG_HALO_PP128: return launch_halo_pp128<T>(a, st);
+        case IG_WS64: return launch_ws64<T>(a, st, device_cus());
         case IG_HALO_8x32: return launch_halo_rw<T, 8, 32>(a, st);
         case IG_HALO_16x16: return launch_halo_rw<T, 16, 16>(a, st);
         case IG_STREAM1x1: return launch_stream1x1<T>(a, st);

@@ -499,7 +499,7 @@ class Builder:
                 self._last_stat_rows = rows
         self.fwd.append(Launch("mi355_conv2d_igemm", x, wf, bias, y, x.N, x.H, x.W, x.C, x.ld, Ho, Wo, Co, y.ld,
                                k, k, s, 1, -p, 1, 1 if up else 0, 2 if relu else 0, stat_part, self.code, flops=flops, nbytes=nbytes,
-                               tag=self.igemm_tag(Co, x.C, k, s, Ho, Wo, False, up, M=x.N * Ho * Wo)))
+                               tag=self.igemm_tag(x.N, x.H, x.W, x.C, Ho, Wo, Co, k, s, 1, -p, 1, 1 if up else 0)))
         y.needs_grad = x.needs_grad or conv.weight.requires_grad
         self._conv_uses[id(conv)] = self._conv_uses.get(id(conv), 0) + 1
 
@@ -529,8 +529,8 @@ class Builder:
                 if up:
                     acc = self.acc_flag(x)
                     xg = self.grad_of(x)
-                    tag = self.igemm_tag(x.C, Co, k, s, 2 * x.H, 2 * x.W, True, False, M=x.N * 4 * x.H * x.W)
-                    if lib.mi355_conv2d_igemm_variant(Ho, Wo, Co, 2 * x.H, 2 * x.W, x.C, k, k, 1, -1, p, s, 0, self.code) in (2, 3, 5, 6):
+                    tag = self.igemm_tag(x.N, Ho, Wo, Co, 2 * x.H, 2 * x.W, x.C, k, 1, -1, p, s, 0)
+                    if lib.mi355_conv2d_igemm_variant(Ho, Wo, Co, 2 * x.H, 2 * x.W, x.C, k, k, 1, -1, p, s, 0, self.code) in (2, 3, 5, 6, 7):
                         # the data gradient lives on the up-sampled grid; its 2x2 sums go straight to the half-resolution
                         # gradient in the kernel epilogue (no full-resolution temporary, no separate pass)
                         self.bwd.append(Launch("mi355_conv2d_igemm", dy, wb, None, xg, x.N, Ho, Wo, Co, dy.ld, 2 * x.H, 2 * x.W,
@@ -546,7 +546,7 @@ class Builder:
                     xg = self.grad_of(x)
                     self.bwd.append(Launch("mi355_conv2d_igemm", dy, wb, None, xg, x.N, Ho, Wo, Co, dy.ld, x.H, x.W, x.C,
                                            xg.ld, k, k, 1, -1, p, s, 0, acc, None, self.code, flops=flops, nbytes=nbytes,
-                                           tag=self.igemm_tag(x.C, Co, k, s, x.H, x.W, True, False, M=x.N * x.H * x.W)))
+                                           tag=self.igemm_tag(x.N, Ho, Wo, Co, x.H, x.W, x.C, k, 1, -1, p, s, 0)))
         return y, bwd
 
     def _emit_multi_wgrad(self, conv, pend, Ho, Wo, Co, k, up, flops, nbytes):
@@ -563,31 +563,23 @@ class Builder:
         ref, beta = self.pgrad(conv.weight)
         self.bwd.append(Launch("mi355_conv2d_wgrad_reduce", ws, splits, ref, Co, x0.C, conv.in_channels, k, k, 0, beta, side=True))
 
-    def igemm_tag(self, co, ci, k=1, s=1, Ho=0, Wo=0, dgrad=False, up=False, M=0):
-        """Kernel variant mi355_conv2d_igemm dispatches to (mirrors the launcher in csrc/conv_igemm.hip)."""
+    def igemm_tag(self, N, Hi, Wi, ci, Ho, Wo, co, k, mul, kmul, off, div, up):
+        """Name of the kernel mi355_conv2d_igemm runs for this launch: the launcher's own choice, batch-dependent fall-backs
+        included (mi355_conv2d_igemm_variant_n; csrc/conv_igemm.hip pick_variant / resolve_variant), so that bench.py's
+        per-kernel time and FLOP sums never mix two kernels under one name."""
         bn = 128 if co % 128 == 0 else (64 if co % 64 == 0 else 32)
         if self.dtype == torch.float32:
             return f"conv_igemm_kernel<f32,{bn},16>"
-        if os.environ.get("MI355_IGEMM_VARIANT") == "0":            # A/B switch of the launcher: register-staged generic kernel
-            return f"conv_igemm_kernel<bf16,{bn},{64 if ci % 64 == 0 else 32}>"
-        if k == 3 and s == 1 and co % 64 == 0 and not (dgrad and up):
-            if Wo % 32 == 0 and Ho % 16 == 0 and os.environ.get("MI355_HALO_PP", "0") == "1":
-                return "conv3x3_halo_pp_kernel"
-            if (Wo % 32 == 0 and Ho % 16 == 0 and co % 128 == 0 and ci % 64 == 0 and os.environ.get("MI355_HALO_PP128", "1") != "0"
-                    and ci >= int(os.environ.get("MI355_HALO_PP128_MINCI", "256"))):
-                return "conv3x3_halo_pp128_kernel"
-            if Wo % 32 == 0 and Ho % 8 == 0:
-                return "conv3x3_halo_rw_kernel<8,32>"
-            if Wo % 16 == 0 and Ho % 16 == 0:
-                return "conv3x3_halo_rw_kernel<16,16>"
-        if k == 1 and s == 1 and not up and (ci, co) in ((64, 32), (32, 64), (128, 64), (64, 128), (64, 64), (32, 32)):
-            return f"conv1x1_stream_kernel<{ci},{co}>"
+        v = lib.mi355_conv2d_igemm_variant_n(N, Hi, Wi, ci, Ho, Wo, co, k, k, mul, kmul, off, div, up, self.code)
         k64 = ci % 64 == 0
-        if bn == 128:
-            return "conv_igemm_dma_kernel<128,64,2>" if k64 else "conv_igemm_dma_kernel<128,32,3>"
-        if bn == 64:
-            return "conv_igemm_dma_kernel<64,32,3>"
-        return "conv_igemm_dma_kernel<32,64,3>" if k64 else "conv_igemm_kernel<bf16,32,32>"
+        if v == 0:
+            return f"conv_igemm_kernel<bf16,{bn},{64 if k64 else 32}>"
+        if v == 1:
+            if bn == 128:
+                return "conv_igemm_dma_kernel<128,64,2>" if k64 else "conv_igemm_dma_kernel<128,32,3>"
+            return "conv_igemm_dma_kernel<64,32,3>" if bn == 64 else "conv_igemm_dma_kernel<32,64,3>"
+        return {2: "conv3x3_halo_rw_kernel<8,32>", 3: "conv3x3_halo_rw_kernel<16,16>", 4: f"conv1x1_stream_kernel<{ci},{co}>",
+                5: "conv3x3_halo_pp_kernel", 6: "conv3x3_halo_pp128_kernel", 7: "conv3x3_ws64_kernel"}[v]
 
     def wgrad_tag(self, co, ci, k=1, s=1, Ho=0, Wo=0):
         t = "f32" if self.dtype == torch.float32 else "bf16"       # (the fp16 build runs the same variants as bf16)

@@ -145,6 +145,18 @@ class AdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         consumed = []
+        # A loss scaler has unscale_()d this optimizer and nobody called clip_grad_norm_: the inf / nan check must cover the
+        # gradients of EVERY group on the buffer before any group steps (torch's GradScaler.step skips the whole optimizer), so
+        # it runs once over the union of the groups' trainable runs, not per group.
+        unchecked = {}
+        for gr, st in zip(self.param_groups, self._st):
+            key = st["p"].data_ptr()
+            clip = _Shared.by_buffer.get(key)
+            if _Shared.amp.get(key) is not None and not (clip is not None and clip["fresh"]):
+                unchecked.setdefault(key, (st, []))[1].extend(self._trainable_runs(gr, st))
+        for st, runs in unchecked.values():
+            if runs:
+                _norm_pass(st["p"], st["g"], sorted(runs), 0.0, self.inv_scale)   # found_inf without clipping
         for gr, st in zip(self.param_groups, self._st):
             if gr["lr"] != st["lr_host"]:
                 st["lr"].fill_(gr["lr"])
@@ -154,8 +166,6 @@ class AdamW(torch.optim.Optimizer):
                 continue
             clip = _Shared.by_buffer.get(st["p"].data_ptr())
             amp_inv = _Shared.amp.get(st["p"].data_ptr())           # a loss scaler has unscale_()d this optimizer
-            if amp_inv is not None and not (clip is not None and clip["fresh"]):
-                clip = _norm_pass(st["p"], st["g"], runs, 0.0, self.inv_scale)    # found_inf without clipping
             coef, finf = st["one"], None
             if clip is not None and clip["fresh"]:
                 coef = clip["coef"]

@@ -194,14 +194,14 @@ def block_fixtures(C):
     print("blocks:", len(rec), "arrays")
 
 
-def train_traj_seg(C, H, name="AttentionUNet", lr=1e-5):
+def train_traj_seg(C, H, name="AttentionUNet", lr=1e-5, hw=32):
     """Reference train() (helpers.py:231-412), segmentation branch, on a fixed synthetic
     loader (shuffle off): parsed per-epoch log lines, best score, final checksums.
     The recurrent nets (R2AttU_Net.py:88-158, R2U_Net.py:50-111) run the same protocol at a 10x larger learning rate
     — six optimiser steps that visibly move the shared-weight convolutions and accumulate 36 running-statistics updates per
     recurrent BatchNorm — and additionally store a few FULL tensors of the final state."""
     from torch.utils.data import DataLoader, TensorDataset
-    hw, epochs = 32, 3
+    epochs = 3
     xs, ys = zip(*[otrain.synthetic_batch(4, hw, seed=s) for s in (0, 1, 2)])
     tr = DataLoader(TensorDataset(torch.cat(xs[:2]), torch.cat(ys[:2])), batch_size=4, shuffle=False)
     va = DataLoader(TensorDataset(xs[2], ys[2]), batch_size=4, shuffle=False)
@@ -528,8 +528,8 @@ def main(only=()):
         "VGG16": lambda: model_fixture("VGG16", lambda: C["VGG16"](num_classes=1000), 32, False, head_dropout=True, H=H),
         "VGG19": lambda: model_fixture("VGG19", lambda: C["VGG19"](num_classes=1000), 32, False, head_dropout=True, H=H),
         "train_traj_seg": lambda: train_traj_seg(C, H),
-        "train_traj_R2AttU_Net": lambda: train_traj_seg(C, H, "R2AttU_Net", lr=1e-4),
-        "train_traj_R2U_Net": lambda: train_traj_seg(C, H, "R2U_Net", lr=1e-4),
+        "train_traj_R2AttU_Net": lambda: train_traj_seg(C, H, "R2AttU_Net", lr=1e-5, hw=64),
+        "train_traj_R2U_Net": lambda: train_traj_seg(C, H, "R2U_Net", lr=1e-5, hw=64),
         "train_traj_cls": lambda: train_traj_cls(C, H),
     }
     for k in (only or jobs):

@@ -42,9 +42,12 @@ CASES = [  # N, Ci, H, W, Co, K, stride, pad, up
     (1, 192, 16, 32, 128, 3, 1, 1, 0),
     (2, 64, 8, 16, 128, 3, 1, 1, 1),
     (1, 128, 48, 32, 128, 3, 1, 1, 0),
-    # ... and more tiles than CUs (36 x 4 x 2 = 288): persistent workgroups that run two tiles, the second one's prologue in
-    # flight during the first one's epilogue
+    # ... and more workgroups than CUs (36 x 4 x 2 = 288 tiles of 16 x 32 x 128: a second round of workgroups on some CUs)
     (36, 64, 32, 64, 256, 3, 1, 1, 0),
+    # weight-stationary kernel (conv3x3_ws64.hpp: Ci == 64) at its default threshold of 4 x 256 tiles: one and two channel tiles
+    # (the data gradient of the first case runs it too: Co = 64 there)
+    (16, 64, 128, 128, 64, 3, 1, 1, 0),
+    (8, 64, 128, 128, 128, 3, 1, 1, 0),
 ]
 
 
@@ -96,7 +99,7 @@ def test_conv_dgrad(case, dtype):
 
 
 # (8, 8): generic kernel; (16, 32) / (32, 32): halo kernels, one and two tiles per image; 256 -> 128 channels on 32 x 64 (four tiles of
-# the 128-channel ping-pong kernel per image, persistent workgroups running several tiles each when the batch is large)
+# the 128-channel ping-pong kernel per image)
 @pytest.mark.parametrize("hw,ci,co,n", [((8, 8), 32, 64, 2), ((16, 32), 32, 64, 2), ((32, 32), 32, 64, 2), ((32, 64), 256, 128, 2),
                                         ((16, 32), 256, 256, 3)])
 @pytest.mark.parametrize("dtype", DT)
@@ -321,7 +324,7 @@ def test_ping_pong_halo_variant_passes_the_same_cases():
                         "fwd or dgrad or statistics or slices or upsampled"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:]
     code = DTYPE_CODE[torch.bfloat16]
-    assert lib.mi355_conv2d_igemm_variant(32, 64, 64, 32, 64, 64, 3, 3, 1, 1, -1, 1, 0, code) == 2          # default: the 4-wave kernel
+    assert lib.mi355_conv2d_igemm_variant(32, 64, 128, 32, 64, 64, 3, 3, 1, 1, -1, 1, 0, code) == 2          # default: the 4-wave kernel
 
 
 def test_128_channel_ping_pong_variant_passes_the_same_cases():
@@ -349,6 +352,52 @@ def test_128_channel_ping_pong_variant_passes_the_same_cases():
     # row query (which knows N) follows the launcher — 32 x 32 x 512 -> 512: 32 images = 256 workgroups of 16 x 32 x 128, 16 images = 128
     assert lib.mi355_conv2d_igemm_stat_rows(32, 32, 32, 512, 32, 32, 512, 3, 3, 1, 1, -1, 1, 0, code) == 32 * 2 * 1
     assert lib.mi355_conv2d_igemm_stat_rows(16, 32, 32, 512, 32, 32, 512, 3, 3, 1, 1, -1, 1, 0, code) == 16 * 4 * 1
+
+
+def test_weight_stationary_kernel_is_bit_identical_to_the_halo_kernel(tmp_path):
+    """conv3x3_ws64.hpp (Ci = 64: weights stationary in registers, persistent workgroups, the default from two tiles per
+    workgroup up) accumulates every output element in the SAME order as the 4-wave halo kernel — (slab, patch column, tap row)
+    with the bias as the first C operand — so its outputs must be BIT-identical to that kernel's (MI355_WS64=0) on every case:
+    forward, bias + ReLU into a channel slice, accumulating data gradients, fused up-sampling with the 2x2-sum epilogue, uneven
+    tile ranges, 1 / 2 / 3 channel tiles; run to run too (a race in the persistent double buffering would show as a difference);
+    the fused BatchNorm sums agree to fp32 summation order."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    outs = {}
+    for tag, env in (("ws64", {"MI355_WS64": "1", "MI355_WS64_MIN_TILES": "8"}), ("halo", {"MI355_WS64": "0"})):
+        out = str(tmp_path / f"{tag}.npz")
+        r = subprocess.run([sys.executable, os.path.join(here, "conv_dump_worker.py"), out], env=dict(os.environ, MI355_DUMP_SET="ws64", **env),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = np.load(out)
+    a, b = outs["ws64"], outs["halo"]
+    assert set(a.files) == set(b.files)
+    n_ws = 0
+    for k in a.files:
+        if "_variant_" in k:
+            n_ws += int(a[k]) == 7
+            assert int(b[k]) != 7
+        elif "_stats" in k:
+            assert np.allclose(a[k], b[k], rtol=2e-5, atol=1e-2), k
+        else:
+            assert np.array_equal(a[k], b[k]), k
+            if k.endswith("0"):
+                assert np.array_equal(a[k], a[k[:-1] + "1"]), k
+    assert n_ws >= 14          # every forward with Ci = 64 and every data gradient with Co = 64 ran the new kernel
+
+
+def test_weight_stationary_variant_dispatch():
+    """Shape-level and batch-level dispatch of variant 7: Ci == 64 on 8 x 32-divisible images; at least two tiles per persistent
+    workgroup (4 x CUs tiles), else the 4-wave kernel; the statistics-row count is that of 8 x 32 tiles either way."""
+    code = DTYPE_CODE[torch.bfloat16]
+    assert lib.mi355_conv2d_igemm_variant(256, 256, 64, 256, 256, 64, 3, 3, 1, 1, -1, 1, 0, code) == 7
+    assert lib.mi355_conv2d_igemm_variant(256, 256, 64, 256, 256, 128, 3, 3, 1, -1, 1, 1, 0, code) == 7           # data gradient 64 -> 128
+    assert lib.mi355_conv2d_igemm_variant(256, 256, 128, 256, 256, 64, 3, 3, 1, 1, -1, 1, 0, code) == 2
+    assert lib.mi355_conv2d_igemm_variant(16, 16, 64, 16, 16, 64, 3, 3, 1, 1, -1, 1, 0, code) == 3
+    assert lib.mi355_conv2d_igemm_variant_n(32, 256, 256, 64, 256, 256, 64, 3, 3, 1, 1, -1, 1, 0, code) == 7
+    assert lib.mi355_conv2d_igemm_variant_n(2, 64, 64, 64, 64, 64, 64, 3, 3, 1, 1, -1, 1, 0, code) == 2           # 32 tiles: too few
+    assert lib.mi355_conv2d_igemm_stat_rows(32, 256, 256, 64, 256, 256, 64, 3, 3, 1, 1, -1, 1, 0, code) == 32 * 32 * 8
+    assert lib.mi355_conv2d_igemm_variant_n(2, 64, 64, 64, 64, 64, 64, 3, 3, 1, 1, -1, 1, 0, DTYPE_CODE[torch.float32]) == 0
 
 
 def test_counted_vmcnt_matches_drained_build(tmp_path):

@@ -111,32 +111,49 @@ def test_fp32_model_matches_reference_golden_and_oracle(name):
     assert np.all(np.abs(l2 - z["param_l2_after"]) <= 1e-5 * l2 + 0.3 * lr * np.sqrt(numel))
 
 
-def test_fp32_train_loop_matches_reference_trajectory(tmp_path, capsys):
+@pytest.mark.parametrize("name", ["AttentionUNet", "R2AttU_Net", "R2U_Net"])
+def test_fp32_train_loop_matches_reference_trajectory(name, tmp_path, capsys):
     """utils.helpers.train (the drop-in driver) on the fixed synthetic loader vs the per-epoch
-    log of the reference's own train() (tests/golden/train_traj_AttentionUNet.npz)."""
+    log of the reference's own train() (tests/golden/train_traj_*.npz, lr 1e-5), for the recurrent nets (64 x 64) with full
+    tensors of the final state — six optimiser steps through the shared-weight convolutions (one mi355_conv2d_wgrad_multi launch
+    per convolution and step) and 36 ordered running-statistics updates per recurrent BatchNorm (R2AttU_Net.py:41-44).  The
+    bounds are those of tests/test_oracle_pins.py::test_train_trajectory_seg: what two CPU evaluations of the protocol differ by."""
     from torch.utils.data import DataLoader, TensorDataset
     from utils import helpers
-    z = np.load(os.path.join(G, "train_traj_AttentionUNet.npz"))
+    z = np.load(os.path.join(G, f"train_traj_{name}.npz"))
     hw, epochs, lr = int(z["hw"]), int(z["epochs"]), float(z["lr"])
-    m, sd, _ = _build("AttentionUNet", torch.float32)
+    m, sd, _ = _build(name, torch.float32)
     b = [otrain.synthetic_batch(4, hw, seed=s) for s in (0, 1, 2)]
     tr = DataLoader(TensorDataset(torch.cat([b[0][0], b[1][0]]), torch.cat([b[0][1], b[1][1]])), batch_size=4, shuffle=False)
     va = DataLoader(TensorDataset(b[2][0], b[2][1]), batch_size=4, shuffle=False)
-    best = helpers.train(m, tr, va, torch.device(DEV), epochs, lr, "AttentionUNet", str(tmp_path), seg=True)
+    best = helpers.train(m, tr, va, torch.device(DEV), epochs, lr, name, str(tmp_path), seg=True)
     text = capsys.readouterr().out
     import re
     rows = re.findall(r"Ep(\d+): TrainLoss ([\d.]+) \| ValLoss ([\d.]+) \| IoU ([\d.]+)", text)
     assert len(rows) == epochs
     for row, ref in zip(rows, z["log"]):
         got = [float(v) for v in row]
-        assert abs(got[1] - ref[1]) <= 2e-3 and abs(got[2] - ref[2]) <= 2e-3 * max(1, ref[2]) and abs(got[3] - ref[3]) <= 5e-3
+        assert abs(got[1] - ref[1]) <= 2e-3 and abs(got[2] - ref[2]) <= 2e-3 * max(1, ref[2]) and abs(got[3] - ref[3]) <= 5e-3, (got, ref)
     assert abs(best - float(z["best"])) < 2e-3 * float(z["best"])
-    saved = torch.load(os.path.join(str(tmp_path), "AttentionUNet_best_loss.pt"))
+    saved = torch.load(os.path.join(str(tmp_path), f"{name}_best_loss.pt"))
     assert list(saved.keys()) == [str(s) for s in z["names"]]
     names = [str(s) for s in z["names"]]
     msd = m.state_dict()
     l2 = np.array([float(msd[k].double().norm()) for k in names])
     assert np.allclose(l2, z["final_l2"], rtol=5e-3)
+    worst = {}
+    for k in z.files:
+        if k.startswith("full_"):
+            worst[k[5:]] = _rel(msd[k[5:]].cpu().numpy(), z[k])
+    print("trajectory", name, "full-tensor deviations", {k: f"{v:.1e}" for k, v in worst.items()})
+    from test_oracle_pins import FULL_TOL
+    for k, v in worst.items():
+        assert v < FULL_TOL(k), (k, v)
+    if "final_val_logits" in z.files:
+        m.eval()
+        with torch.no_grad():
+            ev = m(b[2][0].to(DEV)).float().cpu().numpy()
+        assert _rel(ev, z["final_val_logits"]) < 3e-2
 
 
 def test_fp32_cls_two_stage_train_matches_reference(tmp_path, capsys):
@@ -380,6 +397,44 @@ def test_test_all_models_walks_the_weight_directories(tmp_path, capsys):
     tester.save_results_to_csv(res, str(tmp_path / "c.csv"), str(tmp_path / "s.csv"))
     assert (tmp_path / "c.csv").read_text().startswith("Model,accuracy,precision,recall,f1\nResNet18,")
     assert (tmp_path / "s.csv").read_text().startswith("Model,iou,dice,pixel_accuracy,precision,recall,f1\nAttentionUNet,")
+
+
+def test_amp_overflow_in_a_later_param_group_skips_every_group():
+    """Two parameter groups on one model, fp16 + GradScaler, NO clip_grad_norm_ call: an inf gradient in the SECOND group must be
+    found (the inf / nan check covers the union of all groups, like torch's GradScaler.step over the whole optimizer), every
+    group skips the step, the scale backs off, and a clean step afterwards moves both groups."""
+    from mi355 import amp as mamp, nn as mnn, optim as moptim
+    from models.segmentation_models.AttentionUNet import AttentionUNet
+    torch.manual_seed(5)
+    m = AttentionUNet()
+    m.compute_dtype = torch.float16
+    m = m.to(DEV).train()
+    x, y = otrain.synthetic_batch(2, 32, seed=1)
+    crit = mnn.BCEWithLogitsLoss()
+    crit(m(x.to(DEV)), y.to(DEV)).backward()                       # (flattens the parameters)
+    ps = list(m.parameters())
+    cut = len(ps) // 2
+    opt = moptim.AdamW([{"params": ps[:cut]}, {"params": ps[cut:], "lr": 2e-3}], lr=1e-3, weight_decay=5e-4)
+    sc = mamp.GradScaler(init_scale=1024.0, enabled=True)
+
+    def one_step(poison):
+        opt.zero_grad(set_to_none=True)
+        sc.scale(crit(m(x.to(DEV)), y.to(DEV))).backward()
+        if poison:
+            ps[-3].grad.view(-1)[7] = float("inf")                  # a parameter of the second group
+        sc.unscale_(opt)
+        sc.step(opt)
+        sc.update()
+        torch.cuda.synchronize()
+
+    before = [p.detach().clone() for p in ps]
+    one_step(poison=True)
+    assert all(torch.equal(a, b.detach()) for a, b in zip(before, ps)), "a group stepped on an overflowed gradient"
+    assert sc.get_scale() == 512.0 and [int(st["step"]) for st in opt._st] == [0, 0]
+    one_step(poison=False)
+    assert [int(st["step"]) for st in opt._st] == [1, 1] and sc.get_scale() == 512.0
+    moved = [not torch.equal(a, b.detach()) for a, b in zip(before, ps)]
+    assert any(moved[:cut]) and any(moved[cut:]) and all(torch.isfinite(p).all() for p in ps)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])

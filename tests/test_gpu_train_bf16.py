@@ -5,12 +5,15 @@ BCEWithLogits, clip 1.0, AdamW wd 5e-4) —
 and compare the Dice of the binarised predictions (tester.py:114-134) on 32 held-out images.
 Bound: |Dice - Dice_oracle| <= 1e-3 (0..1 scale) for every GPU mode; final losses within 2 %.
 
-R2AttU_Net (R2AttU_Net.py:88-158, config C4: bf16) runs the same protocol for 8 steps.  Its Dice is still climbing there
-(0.987 -> 0.991 between steps 12 and 20) and 108 shared-weight convolutions per forward make the optimisation trajectory
-chaotic: the fp32 HIP run itself is 2.5e-3 from the oracle at step 12 (and within 1e-3 at step 20), i.e. the distance between
-two trajectories measures summation order, not precision.  The 1e-3 criterion is therefore applied where it is a statement
-about the arithmetic — the ORACLE-TRAINED weights evaluated by the HIP forward in fp32 and bf16 against the oracle's own
-evaluation — and the HIP-trained runs must reach the same quality (Dice within 1e-2, last-batch loss within 20 %)."""
+R2AttU_Net (R2AttU_Net.py:88-158, config C4: bf16) runs the same protocol for 32 steps with the same 1e-3 bound on Dice.  Why
+32: with 108 shared-weight convolutions per forward the early trajectory is chaotic ON THE CPU ALONE — tests/diag/diag_r2_chaos.py
+runs this protocol four ways that differ only in summation order / precision (fp32 with 8 threads, 1 thread, the batch reversed;
+fp64) and those runs are 3.9e-3 apart in Dice at step 8, 1.9e-3 at step 12, 2.4e-4 at step 20 and 4.1e-4 at step 32, where Dice
+has reached its plateau (0.9907-0.9911); their last-batch losses stay 8-20 % apart throughout (tests/test_oracle_kinks.py
+re-measures a short version of this control on every CPU run).  The HIP runs (tests/diag/diag_r2_gpu_traj.py): fp32 0.99088, bf16
+0.99152 at step 32.  So the Dice bound is asserted where it is a statement about arithmetic (the plateau), the loss bound is the
+CPU-vs-CPU spread (15 %), and the ORACLE-TRAINED weights evaluated by the HIP forward must give the oracle's Dice within 1e-3 in
+every precision (no trajectory involved)."""
 import pytest
 import torch
 
@@ -34,7 +37,7 @@ def _dice(logit, m):
 
 @pytest.mark.parametrize("name,steps,dtypes", [
     ("AttentionUNet", 32, (torch.float32, torch.bfloat16, torch.float16)),          # C3 (bf16) and C5's segmenter (fp16)
-    ("R2AttU_Net", 8, (torch.float32, torch.bfloat16)),                            # C4 (bf16)
+    ("R2AttU_Net", 32, (torch.float32, torch.bfloat16)),                           # C4 (bf16)
 ])
 def test_dice_after_training_matches_oracle(name, steps, dtypes):
     from mi355 import nn as mnn, optim as moptim, amp as mamp
@@ -54,7 +57,7 @@ def test_dice_after_training_matches_oracle(name, steps, dtypes):
         ref_dice = _dice(fwd({k: v.clone() for k, v in sd.items()}, xv, True), mv)
     assert ref_dice > 0.95          # the task is learnable: the comparison is not degenerate
     strict = name == "AttentionUNet"
-    dice_tol, loss_tol = (1e-3, 0.02) if strict else (1e-2, 0.20)
+    dice_tol, loss_tol = (1e-3, 0.02) if strict else (1e-3, 0.15)          # (loss: two CPU runs of the R2 protocol are 8-20 % apart, module docstring)
 
     # the oracle-trained weights through the HIP forward: Dice within 1e-3 in every precision (no trajectory involved)
     for dtype in dtypes:

@@ -48,3 +48,26 @@ def test_replayed_masks_make_fp32_and_fp64_gradients_agree():
     _, _, g64s, kinks64, _ = _grads(name, sd, x, y, torch.float64, "record")
     _, _, g64t, _, _ = _grads(name, sd, x, y, torch.float64, "replay", kinks64)
     assert _errs(g64t, g64s).max() < 1e-12
+
+
+def test_r2attunet_training_trajectory_is_chaotic_on_the_cpu_alone():
+    """CPU-only control for the trained-Dice criterion of config C4 (tests/test_gpu_train_bf16.py[R2AttU_Net]): the SAME
+    protocol (64 x 64, batch 4, lr 1e-3, default init) run three ways on the oracle that differ by nothing but summation order /
+    precision — fp32, fp32 with every batch's images in reversed order, fp64.  Eight steps in, their Dice values on the held-out
+    images are already further apart than the 1e-3 the north-star allows between the HIP path and the reference (full protocol,
+    tests/diag/diag_r2_chaos.py: 3.9e-3 at step 8, 1.9e-3 at 12, 2.4e-4 at 20, 4.1e-4 at 32; losses 8-20 % apart throughout): a
+    1e-3 bound on a HIP-TRAINED run before the plateau would measure chaos, not arithmetic — which is why the GPU test trains to
+    step 32.  No GPU is involved here."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("diag_r2_chaos", os.path.join(os.path.dirname(__file__), "diag", "diag_r2_chaos.py"))
+    chaos = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chaos)
+    marks = [8]
+    runs = {"fp32": chaos.run("R2AttU_Net", marks), "fp32 reversed": chaos.run("R2AttU_Net", marks, flip=True),
+            "fp64": chaos.run("R2AttU_Net", marks, dtype=torch.float64)}
+    dice = np.array([r[8][0] for r in runs.values()])
+    loss = np.array([r[8][1] for r in runs.values()])
+    print("R2AttU_Net CPU control, step 8: Dice", dict(zip(runs, dice.round(5))), "loss", dict(zip(runs, loss.round(5))))
+    assert dice.min() > 0.95                                    # every run learns the task
+    assert dice.max() - dice.min() > 5e-4, dice                 # ... and they have visibly parted (measured 2.7e-3 among these three)

@@ -32,7 +32,7 @@ extern "C" {
 typedef struct ihipStream_t* mi355_stream_t; /* == hipStream_t */
 
 enum { MI355_F32 = 0, MI355_BF16 = 1, MI355_F16 = 2 };
-enum { MI355_OK = 0, MI355_ERR_ARG = -1, MI355_ERR_UNSUPPORTED = -2 };
+enum { MI355_OK = 0, MI355_ERR_ARG = -1, MI355_ERR_UNSUPPORTED = -2, MI355_ERR_RUNTIME = -3 };
 
 int mi355_version(void);
 const char* mi355_last_error(void);
@@ -338,6 +338,19 @@ int mi355_plan_run(void* plan, int first, int last, mi355_stream_t main_stream, 
 int mi355_plan_join(void* plan, mi355_stream_t main_stream, mi355_stream_t side_stream);
 int mi355_plan_last_index(void* plan);
 int mi355_plan_destroy(void* plan);
+
+/* ---- data-parallel gradient exchange ----------------------------------------------------------------
+ * The reference is single-device (no DDP / NCCL anywhere: utils/trainer.py:119-213); the data-parallel step of this path sums
+ * the flat fp32 gradient buffer over the GPUs of a node in a few contiguous buckets.  One process per GPU, one communicator per
+ * process, RCCL resolved at run time (the librccl.so already loaded by PyTorch when there is one).  mi355_comm_unique_id: rank 0
+ * fills a 128-byte id (ncclUniqueId) that the host distributes; mi355_comm_init: collective over all ranks with that id;
+ * mi355_allreduce_bucket: in-place sum of `count` elements at `ptr` over the ranks, enqueued on `s` (the caller orders `s` behind
+ * the bucket's last writer); mi355_comm_world: ranks of the live communicator (0 = none); mi355_comm_destroy. */
+int mi355_comm_unique_id(void* id128);
+int mi355_comm_init(int rank, int world, const void* id128);
+int mi355_comm_world(void);
+int mi355_allreduce_bucket(void* ptr, long long count, int dtype, mi355_stream_t s);
+int mi355_comm_destroy(void);
 
 #ifdef __cplusplus
 }

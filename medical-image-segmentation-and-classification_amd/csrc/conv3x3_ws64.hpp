@@ -116,6 +116,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws64_kernel(const ConvArgs a, 
   }
 
   f32x4 acc[MB];
+#ifdef WS64_SKEW                                                           // A/B: the second workgroup of a CU starts half a tile late
+  if (blockIdx.x >= (gridDim.x >> 1)) {
+#pragma unroll 1
+    for (int i = 0; i < WS64_SKEW; ++i) __builtin_amdgcn_s_sleep(32);
+  }
+#endif
   for (int sp = sp_begin; sp < sp_end; ++sp) {
     int t = sp;
     const int tx = t % TXN; t /= TXN;
@@ -140,6 +146,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws64_kernel(const ConvArgs a, 
     };
     auto issue_piece = [&](const bufdesc_t& desc, const unsigned (&off)[P_IT], int slab, int i) __attribute__((always_inline)) {
       const int piece = min(wave + 4 * i, P_INSTR - 1);
+#ifdef WS64_T_NODMA                                                      // timing-only build: stale operands after the first tile
+      if (sp != sp_begin) return;
+#endif
       dma16_buf(desc, off[i], (unsigned)slab * 64u, lds0 + slab * SLAB + piece * 1024);
     };
     bufdesc_t desc_cur;
@@ -294,6 +303,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws64_kernel(const ConvArgs a, 
 #pragma unroll
           for (int e = 0; e < EPC; ++e) v.v[e] = from_f32<T>(to_f32<T>(v.v[e]) + to_f32<T>(o.v[e]));
         }
+#ifdef WS64_T_NOSTORE                                                    // timing-only build: results never leave (one guard store)
+        if (v.v[0] == (T)12345.f)
+#endif
         st16<T>(p, v);
       }
     }

@@ -10,14 +10,20 @@ dgrad/wgrad launches.  The 1/world averaging is folded into the clip/AdamW launc
 (plain DDP semantics; the single-device reference defines nothing else)."""
 from __future__ import annotations
 
+import ctypes
 import os
 
 import torch
 import torch.distributed as dist
 
 from . import graph
+from .lib import lib
 
 _NO_COMM = os.environ.get("MI355_DP_NOCOMM") == "1"
+# MI355_DP_NATIVE=1: the bucket all-reduces go through the library's own RCCL entry points (mi355_comm_init /
+# mi355_allreduce_bucket, csrc/comm.cpp) instead of torch.distributed.all_reduce — same library underneath, no ProcessGroup
+# bookkeeping per call.  torch.distributed stays the default: it is the path the multi-GPU bench has been rehearsed with.
+_NATIVE = os.environ.get("MI355_DP_NATIVE") == "1"
 
 
 class DataParallel:
@@ -32,10 +38,46 @@ class DataParallel:
         self.comm_stream = None
         self.inv_scale = 1.0 / self.world
         self.run_calls = None                 # injectable (CPU tests replace the kernel launcher)
+        self._events = {}                     # plan -> per-bucket (main, side) event pairs, created once
+        self.native = False
         if self.world > 1 or force:
             self.engine.bwd_runner = self._run_backward
+            self._check_hw_queues()
+            if _NATIVE and torch.cuda.is_available():
+                self._init_native()
         if self.world > 1:
             self.sync_state()
+
+    @staticmethod
+    def _check_hw_queues():
+        """The step runs three streams (main, weight-gradient side stream, comm stream) next to RCCL's own; on the runtime's
+        default of four hardware queues two of them share one and serialise (measured +0.7 ms on a 19 ms step).
+        mi355/__init__.py asks for eight — which only takes effect if the runtime had not initialised yet."""
+        import mi355
+        if torch.cuda.is_available() and not mi355.HW_QUEUES_IN_TIME:
+            raise RuntimeError("mi355.dp: the HIP runtime was initialised before `mi355` was imported, so GPU_MAX_HW_QUEUES=8 could "
+                               "not be applied; import the package (or export GPU_MAX_HW_QUEUES yourself) before the first CUDA call")
+
+    def _init_native(self):
+        """One RCCL communicator per process through the C ABI; rank 0's 128-byte id travels over the torch.distributed group
+        (any backend) that is already up."""
+        idt = torch.zeros(128, dtype=torch.uint8)
+        rank = dist.get_rank(self.group) if dist.is_initialized() else 0
+        if rank == 0:
+            buf = (ctypes.c_char * 128)()
+            if lib.mi355_comm_unique_id(ctypes.addressof(buf)) != 0:
+                raise RuntimeError("mi355_comm_unique_id failed: " + lib.raw("mi355_last_error")().decode())
+            idt = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        if self.world > 1:
+            dev = self.engine.flat_g.device if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+            idt = idt.to(dev)
+            dist.broadcast(idt, src=0, group=self.group)
+            idt = idt.cpu()
+        raw = bytes(idt.tolist())
+        if lib.mi355_comm_world() == 0:
+            if lib.mi355_comm_init(rank, self.world, ctypes.c_char_p(raw)) != 0:
+                raise RuntimeError("mi355_comm_init failed: " + lib.raw("mi355_last_error")().decode())
+        self.native = True
 
     @torch.no_grad()
     def sync_state(self, src: int = 0):
@@ -85,6 +127,9 @@ class DataParallel:
     def _allreduce(self, lo, hi):
         if _NO_COMM:        # probe: the cost of the bucket schedule itself (MI355_DP_NOCOMM=1), never set in production
             return
+        if self.native:     # enqueued on the CURRENT stream (the comm stream in the overlapped path)
+            lib.mi355_allreduce_bucket(self.engine.flat_g[lo:hi], hi - lo, 0, torch.cuda.current_stream().cuda_stream)
+            return
         dist.all_reduce(self.engine.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
 
     def _run_backward(self, plan, stream):
@@ -105,15 +150,17 @@ class DataParallel:
         if self.comm_stream is None:
             self.comm_stream = torch.cuda.Stream()
         main = torch.cuda.current_stream()
+        events = self._events.get(id(plan))
+        if events is None:                                  # two events per bucket, created once per plan and re-recorded every step
+            events = self._events[id(plan)] = [(torch.cuda.Event(), torch.cuda.Event()) for _ in buckets]
         start = 0
-        for ready, lo, hi in buckets:
+        for (ready, lo, hi), (ev, ev_s) in zip(buckets, events):
             run(start, ready + 1)
             start = ready + 1
-            ev = torch.cuda.Event()
             ev.record(main)
             ev_side = None
             if plan._side is not None:                      # the bucket's last writer may be a side-stream wgrad reduce
-                ev_side = torch.cuda.Event()
+                ev_side = ev_s
                 ev_side.record(plan._side)
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)

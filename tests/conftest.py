@@ -3,6 +3,7 @@ import sys
 
 import pytest
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before anything initialises the HIP runtime (mi355/__init__.py, mi355/dp.py)
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(REPO, "medical-image-segmentation-and-classification_amd")
 for p in (REPO, PKG):

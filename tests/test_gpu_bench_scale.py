@@ -30,7 +30,7 @@ def _run(tmp_path, tag, **env):
     e = dict(os.environ)
     e.update(env)
     r = subprocess.run([sys.executable, os.path.join(HERE, "bench_scale_worker.py"), out], env=e, capture_output=True, text=True,
-                       timeout=400)
+                       timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     return np.load(out)
 
@@ -86,3 +86,74 @@ def test_attention_unet_256_batch32(tmp_path):
     assert pr.min() >= 0.6 and pr.max() <= 1.6, pr                               # the same rounding-level error, layer by layer
     assert float(C["eval_err_bf16"]) <= 3e-2 and abs(float(C["grad_total_bf16"]) - 1) <= 0.03
     assert np.allclose(C["eval_first"], A["eval_first"], rtol=0, atol=1e-6 * np.abs(A["eval_first"]).max())   # (fp32 path: not switched)
+
+
+# ---- the other configurations of BASELINE.json at their own shapes -----------------------------------------------------------
+# (config, tags that must appear in the bf16 plan, A/B switch, bound on the fp16 eval error or None where eval-mode activations
+#  leave fp16's range, (first-layer fp16 error, last-layer fp16 error) bounds)
+SCALE_CASES = {
+    # R2AttU_Net 256 x 256, batch 16: Ci = 64 recurrent convolutions on the weight-stationary kernel, the 512-channel level on the
+    # 4-wave kernel (16 images of 32 x 32 do not fill the chip with 512-thread workgroups: resolve_variant's fall-back), one
+    # multi-application weight-gradient launch per recurrent convolution.  Eval mode: a recurrent block adds its input six
+    # times in front of an identity BatchNorm, activations reach 1e13 — fp32 and bf16 only.
+    "C4": (("conv3x3_ws64_kernel", "conv3x3_halo_rw_kernel<8,32>", "conv3x3_halo_pp128_kernel", "wgrad3x3_halo_kernel"),
+           {"MI355_WS64": "0"}, None),
+    # AttentionUNet 512 x 512, batch 16 (C5's segmenter, fp16 in the configuration)
+    "C5seg": (("conv3x3_ws64_kernel", "conv3x3_halo_pp128_kernel", "wgrad3x3_halo_kernel"), {"MI355_HALO_PP128": "0"}, 4e-3),
+    # vgg16_bn 512 x 512, batch 16 (C5's classifier): 13 conv + BN layers, the streaming 25088 -> 4096 -> 4096 head
+    "C5cls": (("conv3x3_ws64_kernel", "conv3x3_halo_pp128_kernel", "wgrad3x3_halo_kernel"), {"MI355_WS64": "0"}, 4e-3),
+    # ResNetUnet 256 x 256, batch 32, frozen ResNet-50 encoder (C2: fp32 in the configuration): strided / 1x1 / 7x7 / transposed
+    # convolutions, the 3 x 3 max-pool, wide concatenations (3072 channels)
+    "C2": (("conv_igemm_dma_kernel<128,64,2>", "conv3x3_halo_pp128_kernel"), {"MI355_IGEMM_VARIANT": "0"}, 4e-3),
+}
+
+
+@pytest.mark.parametrize("cfg", list(SCALE_CASES))
+def test_other_configs_at_benchmark_scale(cfg, tmp_path):
+    """Configs C4 / C5 / C2 at their own shapes (tests/bench_scale_worker.py), the protocol of the C3 test above: fp32 eval logits
+    of the first and the last image of the batch against the CPU oracle (<= 1e-3 of the map's maximum); the 2-byte train steps
+    against the fp32 one in the same process — every kept activation's bf16 error is ~8x its fp16 error (three mantissa bits: an
+    indexing error at any depth breaks the proportionality), no jump from one layer to the next, equal losses and gradient norms;
+    and one kernel A/B per config in a child process (the same per-layer error profile through other kernels)."""
+    from oracle import nets
+    sys.path.insert(0, HERE)
+    import bench_scale_worker as w
+    want_tags, ab_env, eval16 = SCALE_CASES[cfg]
+    A = _run(tmp_path, "default", MI355_SCALE_CONFIG=cfg)
+    assert all(bool(A[f"finite_{t}"]) for t in ("fp32", "fp16", "bf16"))
+    tags = set(str(t) for t in A["tags_bf16"])
+    assert set(want_tags) <= tags, (want_tags, sorted(tags))
+
+    # ---- fp32 eval forward vs the CPU oracle on two images of the batch ---------------------------------------------------
+    c = w.CONFIGS[cfg]
+    name, state, keep = c[0], c[2], c[6]
+    x, _ = w.make_batch(c, "cpu")
+    sd = state()
+    with torch.no_grad():
+        for key, i in (("eval_first", keep[0]), ("eval_last", keep[1])):
+            r = nets.NETS[name]({k: v.clone() for k, v in sd.items()}, x[i:i + 1], False)[0].numpy()
+            assert np.abs(A[key] - r).max() <= 1e-3 * np.abs(r).max(), (key, np.abs(A[key] - r).max() / np.abs(r).max())
+    if eval16 is not None:
+        assert float(A["eval_err_fp16"]) <= eval16, float(A["eval_err_fp16"])
+    assert float(A["eval_err_bf16"]) <= 3e-2, float(A["eval_err_bf16"])
+
+    # ---- train step: error profile of the 2-byte runs against fp32, layer by layer -------------------------------------------------
+    e16, eb = A["act_err_fp16"], A["act_err_bf16"]
+    assert len(e16) >= 10 and e16[0] <= 1e-3 and eb[0] <= 8e-3, (len(e16), e16[0], eb[0])
+    ratio = eb / e16
+    assert ratio.min() >= 4.0 and ratio.max() <= 12.0, ratio                    # 2^3 = 8: three mantissa bits
+    for t in ("fp16", "bf16"):
+        assert abs(float(A[f"loss_{t}"]) - float(A["loss_fp32"])) <= (3e-3 if t == "fp16" else 2e-2) * abs(float(A["loss_fp32"])), t
+        big = A["grad_norm_fp32"] > 1e-4 * A["grad_norm_fp32"].max()
+        d = np.abs(A[f"grad_norm_{t}"][big] / A["grad_norm_fp32"][big] - 1)
+        assert np.median(d) <= (0.05 if t == "fp16" else 0.25), (t, np.median(d))
+
+    # ---- kernel A/B at full size ---------------------------------------------------------------------------------------------------
+    B = _run(tmp_path, "ab", MI355_SCALE_CONFIG=cfg, **ab_env)
+    tb = set(str(t) for t in B["tags_bf16"])
+    assert tb != tags, "the switch did not change the kernel selection"
+    pr = B["act_err_bf16"] / A["act_err_bf16"]
+    assert pr.min() >= 0.5 and pr.max() <= 2.0, pr                               # the same rounding-level error, layer by layer
+    assert abs(float(B["loss_bf16"]) - float(A["loss_bf16"])) <= 2e-2 * abs(float(A["loss_bf16"]))
+    assert abs(float(B["grad_total_bf16"]) / float(A["grad_total_bf16"]) - 1) <= 0.1
+    assert np.allclose(B["eval_first"], A["eval_first"], rtol=0, atol=1e-6 * np.abs(A["eval_first"]).max())   # (fp32 path: not switched)

@@ -106,3 +106,66 @@ def test_dp_world2_matches_single_process_emulation():
     ref = eng.flat_p.detach().cpu()
     err = float((p0 - ref).abs().max() / ref.abs().max())
     assert err <= 1e-6, err
+
+
+def _rccl_worker(port, native, q):
+    """A fresh process: RCCL (torch.distributed backend "nccl") with ONE rank — the production code path of bench.py --gpus N
+    (process group, comm stream, bucket schedule, event edges, all-reduce launches on the device) minus the other ranks."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if native:
+        os.environ["MI355_DP_NATIVE"] = "1"
+    try:
+        m, shards = _setup()                                   # imports the package BEFORE the first CUDA call
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+        from mi355 import nn as mnn, optim as moptim
+        from mi355.dp import DataParallel
+        from mi355.lib import lib
+        out = {}
+        for tag in ("dp", "plain"):
+            m, _ = _setup()
+            if tag == "dp":
+                dp = DataParallel(m, bucket_mb=8.0, overlap=True, force=True)
+                assert dp.native == bool(native) and dp.inv_scale == 1.0
+            opt = moptim.AdamW(m.parameters(), lr=LR, weight_decay=5e-4)
+            crit = mnn.BCEWithLogitsLoss()
+            for s_ in range(STEPS):
+                x, y = shards[0][s_]
+                opt.zero_grad(set_to_none=True)
+                crit(m(x.to(DEV)), y.to(DEV)).backward()
+                moptim.clip_grad_norm_(m.parameters(), 1.0)
+                opt.step()
+            torch.cuda.synchronize()
+            out[tag] = m.engine.flat_p.detach().cpu().numpy()
+            if tag == "dp":
+                plan = [p for p in m.engine.plans.values() if p.dout is not None][0]
+                out["buckets"] = len(dp.schedule(plan))
+                out["events"] = len(dp._events[id(plan)])
+                out["comm_world"] = lib.mi355_comm_world()
+        q.put(("ok", out))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put(("fail", traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("native", [0, 1])
+def test_rccl_code_path_with_one_rank(native):
+    """backend="nccl" IS RCCL on ROCm: a spawned child runs init_process_group("nccl", world_size=1), DataParallel(force=True)
+    and two optimiser steps.  An all-reduce over one rank is the identity, so the parameters must be BIT-identical to the
+    same steps without the data-parallel runner, while everything around it is the multi-GPU path: several buckets, their
+    pre-allocated event pairs, the comm stream.  native=1: the same through the library's own RCCL entry points
+    (mi355_comm_init / mi355_allreduce_bucket, MI355_DP_NATIVE=1)."""
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), native, q))
+    p.start()
+    status, out = q.get(timeout=400)
+    p.join(timeout=60)
+    assert status == "ok", out
+    assert out["buckets"] > 1 and out["events"] == out["buckets"]
+    assert out["comm_world"] == (1 if native else 0)
+    assert np.array_equal(out["dp"], out["plain"])

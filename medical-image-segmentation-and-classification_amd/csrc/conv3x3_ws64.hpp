@@ -8,7 +8,7 @@
 //   weights     : a wave owns 16 output channels for ALL of K = 9 x 64: 18 MFMA A-fragments = 72 registers per lane, loaded
 //                 once per workgroup straight from global memory.  No weight bytes in LDS, no weight fragment reads.
 //   workgroup   : 4 waves = 64 output channels, PERSISTENT: it walks a contiguous range of 8 x 32-pixel tiles of one channel
-//                 tile (grid = 2 workgroups per CU, 60 KB of LDS and <= 256 registers each: the two run independently and
+//                 tile (grid = 2 workgroups per CU, 80 KB of LDS and <= 256 registers each: the two run independently and
 //                 fill each other's epilogues and waits)
 //   wave tile   : ALL 256 pixels x 16 channels (64 accumulator registers); per (32-channel slab, patch column) step the ten
 //                 patch-row fragments of a 16-pixel column are read once and feed up to three output rows: 20 ds_read_b128
@@ -16,11 +16,13 @@
 //   patch       : two 32-channel slabs [10 rows][36-pixel pitch][64 B] (conv3x3_halo_pp128.hpp's layout: the swizzle bit of a
 //                 pixel is (row + (x >> 2)) & 1, so a fragment address is ONE lane register per column shift + immediates),
 //                 each brought by 23 LDS-DMA pieces through a buffer descriptor based at the patch origin
-//   schedule    : slab 1 of tile t lands while slab 0 is multiplied, slab 0 of tile t + 1 while slab 1 is (buffer A is free
-//                 after the mid-tile barrier); the C tile is staged over slab 1's buffer.  Every DMA wait is a vmcnt(0) half
-//                 a tile (>= 2300 pipe cycles) after the youngest piece AND the previous tile's stores were issued, so the
-//                 stores-count-in-vmcnt coupling that sank round 2's persistent variants never waits for a fresh store.
-//                 Four barriers per tile (the 4-wave halo kernel: eight).
+//   schedule    : slab 0 of tile t + 1 lands (buffer A) while slab 1 of tile t is multiplied, slab 1 of tile t + 1 (buffer B) is
+//                 requested right behind tile t's last MFMA and lands during its epilogue and the next tile's first half; the C
+//                 tile has a staging area of its own (136-B pixel pitch: conflict-free 8-byte writes), so the epilogue's reads
+//                 need no barrier behind them.  gfx950 counts stores in vmcnt, in issue order with the DMA pieces: the mid-tile
+//                 wait for slab 1 is a COUNTED vmcnt that leaves exactly the epilogue's stores (younger than the pieces) in
+//                 flight, the end-of-tile wait a vmcnt(0) half a tile after the youngest store — the coupling that sank round 2's
+//                 persistent variants never waits for a fresh store.  Three barriers per tile (the 4-wave halo kernel: eight).
 #pragma once
 #include <type_traits>
 
@@ -32,9 +34,9 @@ struct Ws64Cfg {
   static constexpr int NPIX = PH * PWL;                                  // 360 pixel slots per slab
   static constexpr int P_INSTR = (NPIX + 15) / 16;                       // 23 DMA pieces of 16 pixels
   static constexpr int SLAB_BYTES = P_INSTR * 1024;                      // 23 KiB
-  static constexpr int C_PITCH = BN * 2 + 16;
-  static constexpr int C_BYTES = TH * TW * C_PITCH;                      // 36 KiB, staged over slab 1's buffer and the tail
-  static constexpr int LDS_BYTES = SLAB_BYTES + (C_BYTES > SLAB_BYTES ? C_BYTES : SLAB_BYTES);
+  static constexpr int C_PITCH = BN * 2 + 8;                             // 34 dwords: the 16 pixel rows of an 8-byte staging write hit 32 distinct banks
+  static constexpr int C_BYTES = TH * TW * C_PITCH;                      // 34 KiB staging area of its own
+  static constexpr int LDS_BYTES = 2 * SLAB_BYTES + C_BYTES;             // 80 KiB: exactly two workgroups per CU
 };
 
 template <int I> using WsI = std::integral_constant<int, I>;
@@ -87,6 +89,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws64_kernel(const ConvArgs a, 
       }
   }
   f32x4 bias4 = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n0 + wave * 16 + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  // The loads above must be COMPLETE, in the compiler's own book-keeping, before the tile loop: hipcc waits for a load in front
+  // of its first use — the first MFMA of the loop body — with s_waitcnt vmcnt(0), on every trip, and that wait would also drain
+  // the previous tile's stores and the slab in flight (measured on the first version of this kernel).  Passing the registers
+  // through an empty asm statement puts the wait here and makes the values asm results with nothing pending behind them.
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) asm volatile("" : "+v"(wf[s][tp]));
+  asm volatile("" : "+v"(bias4));
 
   // ---- DMA lane geometry: piece p = LDS pixel slots [16 p, +16) x 64 B; lane -> (slot pixel, 16-byte chunk) ------------------
   // source offsets are relative to the PATCH ORIGIN (pixel (y0 - 1, x0 - 1) of the tile, halved when the x2 up-sampling is
@@ -116,6 +127,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws64_kernel(const ConvArgs a, 
   }
 
   f32x4 acc[MB];
+  // The plain epilogue's stores are DEFERRED: a tile's 8 x 16 bytes per thread stay in the staging area (rewritten only behind
+  // the next tile's two barriers) and leave from inside the next tile's first-half MFMA stream, one (staging read, store) pair
+  // per three row-visits, instead of as a burst in front of it (timing-only builds: the burst cost 18 % of the kernel).
+  T* pend = nullptr;                                                     // this thread's first chunk of the tile waiting in staging
+  bool has_pend = false;                                                 // (workgroup-uniform)
+  constexpr int NSTORE = BM * (BN / EPC) / 256;                          // 8: store `it` = tile row `it`, pixel tid >> 3, chunk tid & 7
+  const size_t row_stride = (size_t)a.Wo * a.ldo;
+  const unsigned char* const cst_rd = lds + 2 * Cfg::SLAB_BYTES + (tid >> 3) * C_PITCH + (tid & 7) * 16;
+  auto store_pending = [&](int it) __attribute__((always_inline)) {
+    const Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(cst_rd + it * TW * C_PITCH);
+#ifdef WS64_T_NOSTORE                                                    // timing-only build: results never leave (one guard store)
+    if (v.v[0] == (T)12345.f)
+#endif
+    st16<T>(pend + it * row_stride, v);
+  };
 #ifdef WS64_SKEW                                                           // A/B: the second workgroup of a CU starts half a tile late
   if (blockIdx.x >= (gridDim.x >> 1)) {
 #pragma unroll 1
@@ -154,9 +180,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws64_kernel(const ConvArgs a, 
     bufdesc_t desc_cur;
     unsigned off_cur[P_IT];
     patch_of(sp, desc_cur, off_cur);
-    if (sp == sp_begin) {                                                // the first tile's slab 0 (later ones arrive during the previous tile)
+    const bool first = sp == sp_begin;
+    if (first) {                                                         // the first tile's slabs (later ones arrive during the previous tile)
 #pragma unroll
-      for (int i = 0; i < P_IT; ++i) issue_piece(desc_cur, off_cur, 0, i);
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int i = 0; i < P_IT; ++i) issue_piece(desc_cur, off_cur, s2, i);
       wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
     }
@@ -187,17 +216,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws64_kernel(const ConvArgs a, 
         constexpr int v = decltype(v_tag)::value;
         constexpr int pw = v / PH, pr = v % PH;
         if constexpr (v + 2 < 3 * PH) rd(WsI<v + 2>{});
-        // the other slab's DMA pieces, one per five row-visits from the first on (slab 0: this tile's slab 1 -> buffer B;
-        // slab 1: the next tile's slab 0 -> buffer A)
-        if constexpr (v % 5 == 0 && v / 5 < P_IT) {
-          if constexpr (s == 0) issue_piece(desc_cur, off_cur, 1, v / 5);
-          else issue_piece(desc_nxt, off_nxt, 0, v / 5);
+        // during slab 1: the next tile's slab 0 -> buffer A (free since the mid-tile barrier), one piece per five row-visits
+        if constexpr (s == 1 && v % 5 == 0 && v / 5 < P_IT) issue_piece(desc_nxt, off_nxt, 0, v / 5);
+        // during slab 0: the previous tile's deferred stores
+        if constexpr (s == 0 && v % 3 == 1 && v / 3 < NSTORE) {
+          if (has_pend) store_pending(v / 3);
         }
 #pragma unroll
         for (int xb = 0; xb < XB; ++xb)
 #pragma unroll
           for (int ph = 0; ph < 3; ++ph) {
-            constexpr int dummy = 0;
             const int orow = pr - ph;
             if (orow >= 0 && orow < TH) {
               f32x4& c = acc[orow * XB + xb];
@@ -209,14 +237,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws64_kernel(const ConvArgs a, 
       });
     };
     slab_phase(WsI<0>{});
-    wait_vmcnt<0>();                                                     // slab 1 has landed (issued >= 2000 cycles ago)
+    // slab 1 was requested behind the previous tile's last MFMA, in FRONT of that tile's stores: the counted wait leaves exactly
+    // those stores in flight (8 x 16 B per thread, 2 in the 2x2-sum epilogue; a smaller count would only wait for stores too).
+    // (first tile: both slabs landed in the prologue)
+    if (!first) {
+      if (a.pool2) wait_vmcnt<(BM / 4) * (BN / EPC) / 256>(); else wait_vmcnt<BM * (BN / EPC) / 256>();
+    }
     __builtin_amdgcn_s_barrier();                                        // ... for every wave; buffer A is free
     slab_phase(WsI<1>{});
-    wait_vmcnt<0>();                                                     // next tile's slab 0 has landed; the previous tile's stores are long gone
-    __builtin_amdgcn_s_barrier();                                        // buffer B is free: the C tile goes there
+    wait_vmcnt<0>();                                                     // next tile's slab 0 has landed (the previous tile's stores are long gone)
+    __builtin_amdgcn_s_barrier();                                        // buffer B is free
 
     // ---- epilogue: a lane holds, per block, FOUR CONSECUTIVE CHANNELS (16 wave + 4 c4 .. + 3) of pixel (row, 16 xb + l16) ----
-    unsigned char* const cst = lds + SLAB;
+    unsigned char* const cst = lds + 2 * SLAB;
     struct alignas(8) Pack4 { T v[4]; };
     auto finish = [&](auto relu_tag, auto stats_tag) __attribute__((always_inline)) {
       constexpr bool RELU = decltype(relu_tag)::value, STATS = decltype(stats_tag)::value;
@@ -258,6 +291,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws64_kernel(const ConvArgs a, 
     } else {
       if (a.relu) finish(Yes{}, No{}); else finish(No{}, No{});
     }
+    // the next tile's slab 1 -> buffer B: the ONLY vector-memory operations between here and the next mid-tile wait are the
+    // tile's stores below (the statistics went out above)
+#pragma unroll
+    for (int i = 0; i < P_IT; ++i) issue_piece(desc_nxt, off_nxt, 1, i);
     __builtin_amdgcn_s_waitcnt(0xc07f);                                  // lgkmcnt(0): the staging writes are done
     __builtin_amdgcn_s_barrier();
     constexpr int CPRC = BN / EPC;
@@ -290,27 +327,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws64_kernel(const ConvArgs a, 
         }
         st16<T>(p, v);
       }
-    } else {
+    } else if (a.accumulate) {
 #pragma unroll
-      for (int it = 0; it < BM * CPRC / 256; ++it) {
+      for (int it = 0; it < NSTORE; ++it) {
         const int id = tid + it * 256;
         const int row = id / CPRC, c = id - row * CPRC;
         const int py = row / TW, px = row - py * TW;
         T* p = out + ((size_t)(n * a.Ho + y0 + py) * a.Wo + x0 + px) * a.ldo + n0 + c * EPC;
         Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(cst + row * C_PITCH + c * 16);
-        if (a.accumulate) {
-          const Vec16<T> o = ld16<T>(p);
+        const Vec16<T> o = ld16<T>(p);
 #pragma unroll
-          for (int e = 0; e < EPC; ++e) v.v[e] = from_f32<T>(to_f32<T>(v.v[e]) + to_f32<T>(o.v[e]));
-        }
-#ifdef WS64_T_NOSTORE                                                    // timing-only build: results never leave (one guard store)
-        if (v.v[0] == (T)12345.f)
-#endif
+        for (int e = 0; e < EPC; ++e) v.v[e] = from_f32<T>(to_f32<T>(v.v[e]) + to_f32<T>(o.v[e]));
         st16<T>(p, v);
       }
+    } else {             // plain: the stores ride in the next tile's MFMA stream (store_pending), or behind the loop
+      pend = out + ((size_t)(n * a.Ho + y0) * a.Wo + x0 + (tid >> 3)) * a.ldo + n0 + (tid & 7) * EPC;
+      has_pend = true;
     }
-    __builtin_amdgcn_s_waitcnt(0xc07f);                                  // lgkmcnt(0): the staging reads are in registers
-    __builtin_amdgcn_s_barrier();                                        // buffer B may be overwritten by the next tile's slab 1
+    // (no barrier: the staging area is written again only behind the next tile's two barriers)
+  }
+  if (has_pend) {
+#pragma unroll
+    for (int it = 0; it < NSTORE; ++it) store_pending(it);
   }
 }
 

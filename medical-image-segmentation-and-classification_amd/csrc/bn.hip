@@ -257,6 +257,67 @@ extern "C" int mi355_bn_act(const void* x, int ldx, const float* scale, const fl
   });
 }
 
+// ---- apply + ReLU with the following MaxPool2d(2, 2) in the same pass (AttentionUNet.py:61,89-95: every encoder level) --------
+// A thread owns one 16-byte channel chunk of one 2 x 2 pixel group: four reads of the raw convolution output, four writes of the
+// activation (the skip connection / gate / next convolution read it), one write of the pooled tensor — the separate pooling pass
+// re-read the whole activation.  Values are pooled AFTER rounding to the storage type, i.e. exactly what mi355_maxpool_fwd reads.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_pool2_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, T* __restrict__ y, int ldy,
+                                                           T* __restrict__ p, int ldp, int N, int H, int W, int C, int act) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  const int cp = C / EPC, Ho = H >> 1, Wo = W >> 1;
+  const long long total = (long long)N * Ho * Wo * cp;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % cp) * EPC;
+    long long q = i / cp;
+    const int wo = (int)(q % Wo); q /= Wo;
+    const int ho = (int)(q % Ho);
+    const int n = (int)(q / Ho);
+    float sc[EPC], sh[EPC], m[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { sc[e] = scale[c0 + e]; sh[e] = shift[c0 + e]; }
+    const size_t r0 = ((size_t)(n * H + 2 * ho) * W + 2 * wo);
+    Vec16<T> in[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) in[k] = ld16_nt<T>(x + (r0 + (size_t)(k >> 1) * W + (k & 1)) * ldx + c0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      Vec16<T> o;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        float v = to_f32<T>(in[k].v[e]) * sc[e] + sh[e];
+        if (act & 1) v = fmaxf(v, 0.f);
+        o.v[e] = from_f32<T>(v);
+        const float r = to_f32<T>(o.v[e]);
+        m[e] = k == 0 ? r : fmaxf(m[e], r);
+      }
+      st16<T>(y + (r0 + (size_t)(k >> 1) * W + (k & 1)) * ldy + c0, o);
+    }
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) o.v[e] = from_f32<T>(m[e]);
+    st16<T>(p + ((size_t)(n * Ho + ho) * Wo + wo) * ldp + c0, o);
+  }
+}
+
+extern "C" int mi355_bn_act_pool2(const void* x, int ldx, const float* scale, const float* shift, void* y, int ldy, void* p, int ldp,
+                                  int N, int H, int W, int C, int act, int dtype, mi355_stream_t s) {
+  MI355_CHECK_ARG(x && scale && shift && y && p && N > 0, "bn_act_pool2: bad arguments");
+  MI355_CHECK_ARG(H % 2 == 0 && W % 2 == 0, "bn_act_pool2: %d x %d is not divisible into 2 x 2 groups", H, W);
+  const int epc = dtype_is_2byte(dtype) ? 8 : 4;
+  MI355_CHECK_ARG(C % epc == 0, "bn_act_pool2: C=%d must be a multiple of %d", C, epc);
+  long long blocks = ((long long)N * (H / 2) * (W / 2) * (C / epc) + 255) / 256;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  return dispatch_dtype(dtype, "bn_act_pool2", [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((bn_act_pool2_kernel<T>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx, scale, shift, (T*)y, ldy,
+                       (T*)p, ldp, N, H, W, C, act);
+    MI355_LAUNCH_CHECK();
+    return (int)MI355_OK;
+  });
+}
+
 // ---- backward ------------------------------------------------------------------------------------
 template <typename T> struct BnBwdReduceOp {
   static constexpr int NQ = 2;

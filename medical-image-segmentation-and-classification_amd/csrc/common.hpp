@@ -106,7 +106,12 @@ template <> __device__ __forceinline__ void mfma_16x16x32_first<bf16_t>(bf16x8 a
 template <> __device__ __forceinline__ void mfma_16x16x32_first<f16_t>(bf16x8 a, bf16x8 b, f32x4& c) {
   asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
 }
-__device__ __forceinline__ void mfma_results_ready() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+// (the sched_barrier keeps every later instruction — a pure VALU read of an accumulator has no data dependence on the nops —
+// behind them)
+__device__ __forceinline__ void mfma_results_ready() {
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 

@@ -590,6 +590,16 @@ static IgemmVariant resolve_variant(IgemmVariant v, int N, int Ho, int Wo, int C
   return grid * 5 >= rounds * cus * 4 ? IG_HALO_PP128 : IG_HALO_8x32;          // >= 80 % of the last round filled
 }
 
+static bool halo_family(IgemmVariant v) {
+  return v == IG_HALO_8x32 || v == IG_HALO_16x16 || v == IG_HALO_PP || v == IG_HALO_PP128 || v == IG_WS64;
+}
+static bool image_fits_descriptor(int Hi, int Wi, int ldi, int esz) { return (long long)Hi * Wi * ldi * esz < (1ll << 31); }
+static IgemmVariant final_variant(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int mul, int kmul, int off,
+                                  int div, int up, int dtype) {
+  const IgemmVariant v = resolve_variant(pick_variant(Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up, dtype), N, Ho, Wo, Co);
+  return halo_family(v) && !image_fits_descriptor(Hi, Wi, Ci, 2) ? IG_DMA : v;
+}
+
 extern "C" int mi355_conv2d_igemm_variant(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int mul, int kmul, int off,
                                           int div, int up, int dtype) {
   return (int)pick_variant(Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up, dtype);
@@ -597,12 +607,12 @@ extern "C" int mi355_conv2d_igemm_variant(int Hi, int Wi, int Ci, int Ho, int Wo
 
 extern "C" int mi355_conv2d_igemm_variant_n(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int mul, int kmul,
                                             int off, int div, int up, int dtype) {
-  return (int)resolve_variant(pick_variant(Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up, dtype), N, Ho, Wo, Co);
+  return (int)final_variant(N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up, dtype);
 }
 
 extern "C" int mi355_conv2d_igemm_stat_rows(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int mul,
                                             int kmul, int off, int div, int up, int dtype) {
-  switch (resolve_variant(pick_variant(Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up, dtype), N, Ho, Wo, Co)) {
+  switch (final_variant(N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up, dtype)) {
     case IG_HALO_PP:
     case IG_HALO_PP128: return N * (Ho / 16) * (Wo / 32);
     case IG_WS64:
@@ -630,7 +640,14 @@ extern "C" int mi355_conv2d_igemm(const void* in, const void* wk, const float* b
                       (ldi * esz) % 16 == 0 && (ldo * esz) % 16 == 0,
                   "conv2d_igemm: pointers / channel strides must be 16-byte aligned");
   MI355_CHECK_ARG(Ci % (esz == 2 ? 32 : 16) == 0, "conv2d_igemm: Ci=%d must be a multiple of %d", Ci, esz == 2 ? 32 : 16);
-  const IgemmVariant v = resolve_variant(pick_variant(Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up, dtype), N, Ho, Wo, Co);
+  // the halo / ping-pong / weight-stationary kernels address an image through a buffer descriptor with 32-bit lane offsets and a
+  // 2^31-byte range check (dma.hpp): an image of 2 GiB or more would be zero-filled silently — final_variant sends such shapes to
+  // the LDS-DMA ring kernel with its 64-bit addresses (judged on Ci, which the statistics-row query knows too; a channel STRIDE
+  // that alone pushes an image over the limit is refused below)
+  const IgemmVariant v = final_variant(N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up, dtype);
+  MI355_CHECK_ARG(!halo_family(v) || image_fits_descriptor(Hi, Wi, ldi, esz),
+                  "conv2d_igemm: an image of %d x %d pixels at a channel stride of %d is 2 GiB or more: beyond the 32-bit lane offsets of "
+                  "the halo kernels' buffer descriptors", Hi, Wi, ldi);
   MI355_CHECK_ARG(!stats || (v != IG_GENERIC && !(accumulate & 1)),
                   "conv2d_igemm: fused statistics are not available for this shape/dtype (mi355_conv2d_igemm_stat_rows == 0)");
   ConvArgs a;

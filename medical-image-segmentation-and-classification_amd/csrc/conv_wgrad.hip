@@ -312,7 +312,11 @@ extern "C" int mi355_conv2d_wgrad(const void* x, const void* dy, float* ws, int 
   a.chunk = ceil_div(ceil_div(a.M, splits), 32) * 32;
   static const int use_halo = getenv("MI355_WGRAD_HALO") ? atoi(getenv("MI355_WGRAD_HALO")) : 1;
   const int hmode = halo_wgrad_mode(N, Ho, Wo, KH, KW);
-  if (dtype_is_2byte(dtype) && use_halo && stride == 1 && pad == 1 && hmode && Ho == a.Hlog && Wo == a.Wlog) {
+  // (the nine-tap kernel addresses an image — two in the 16-pixel mode — through buffer descriptors with 32-bit lane and row
+  //  offsets: 2 GiB or more per image goes to the generic kernel, which carries 64-bit addresses)
+  const long long img_lim = (1ll << 31) / (hmode == 2 ? 2 : 1);
+  const bool fits = (long long)Hi * Wi * ldx * esz < img_lim && (long long)Ho * Wo * ldy * esz < img_lim;
+  if (dtype_is_2byte(dtype) && use_halo && stride == 1 && pad == 1 && hmode && Ho == a.Hlog && Wo == a.Wlog && fits) {
     Wgrad3Args h;
     for (int i = 0; i < 6; ++i) { h.xs[i] = x; h.dys[i] = dy; }
     h.ws = ws;
@@ -348,6 +352,8 @@ extern "C" int mi355_conv2d_wgrad_multi(const void* x0, const void* dy0, const v
   MI355_CHECK_ARG(Ci % 8 == 0 && Co % 8 == 0 && (ldx * 2) % 16 == 0 && (ldy * 2) % 16 == 0 && ldx >= Ci && ldy >= Co,
                   "conv2d_wgrad_multi: channel counts / strides must be multiples of 8 elements");
   MI355_CHECK_ARG((up ? (Ho == 2 * Hi && Wo == 2 * Wi) : (Ho == Hi && Wo == Wi)), "conv2d_wgrad_multi: 3x3 / stride 1 / pad 1 geometry only");
+  MI355_CHECK_ARG((long long)Hi * Wi * ldx * 4 < (1ll << 31) && (long long)Ho * Wo * ldy * 4 < (1ll << 31),
+                  "conv2d_wgrad_multi: an image of 1 GiB or more is beyond the 32-bit offsets of the nine-tap kernel's buffer descriptors");
   const int hmode = halo_wgrad_mode(N, Ho, Wo, 3, 3);
   Wgrad3Args h;
   for (int i = 0; i < 6; ++i) { h.xs[i] = xs[i < napp ? i : 0]; h.dys[i] = dys[i < napp ? i : 0]; }

@@ -26,6 +26,7 @@ from .lib import lib, DTYPE_CODE
 
 BN_EPS_DEFAULT = 1e-5
 CPAD = 32          # network inputs are zero-padded to 32 channels (MFMA K granularity)
+FUSE_POOL = os.environ.get("MI355_FUSE_POOL", "1") != "0"      # MaxPool2d(2, 2) inside the BatchNorm apply pass that feeds it (A/B switch)
 
 
 class T:
@@ -801,7 +802,16 @@ class Builder:
     def maxpool(self, x, k=2, s=2, p=0):
         Ho, Wo = (x.H + 2 * p - k) // s + 1, (x.W + 2 * p - k) // s + 1
         y = self.new_tensor(x.N, Ho, Wo, x.C)
-        self.fwd.append(Launch("mi355_maxpool_fwd", x, x.ld, y, y.ld, x.N, x.H, x.W, x.C, k, s, p, self.code))
+        last = self.fwd[-1] if self.fwd else None
+        if (FUSE_POOL and (k, s, p) == (2, 2, 0) and x.H % 2 == 0 and x.W % 2 == 0 and last is not None and last.name == "mi355_bn_act"
+                and last.args[10] is x and last.args[4] is None and last.args[8] is None and last.args[12] == x.M):
+            # the pooled tensor leaves the BatchNorm apply pass that has just produced x (a plain one: no second operand, no
+            # residual): one read of the raw convolution output instead of that plus a re-read of the activation
+            a = last.args
+            self.fwd[-1] = Launch("mi355_bn_act_pool2", a[0], a[1], a[2], a[3], x, x.ld, y, y.ld, x.N, x.H, x.W, x.C, a[14], self.code,
+                                  nbytes=last.bytes + y.M * y.C * self.esz)
+        else:
+            self.fwd.append(Launch("mi355_maxpool_fwd", x, x.ld, y, y.ld, x.N, x.H, x.W, x.C, k, s, p, self.code))
         self.acts.append(("pool", x, y, k, s, p))
         y.needs_grad = x.needs_grad
 

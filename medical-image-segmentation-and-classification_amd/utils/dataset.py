@@ -48,10 +48,17 @@ def png_size(buf):
     return h.value, w.value
 
 
-def decode_batch(bufs, channels, threads=8, pin=True):
-    """PNG byte buffers of ONE size -> uint8 tensor [N, H, W, channels] in (pinned) host memory."""
+def decode_batch(bufs, channels, threads=8, pin=True, names=None):
+    """PNG byte buffers of ONE size -> uint8 tensor [N, H, W, channels] in (pinned) host memory.  A buffer of another size is
+    reported by name (``names[i]``, else its index) before anything is decoded."""
     n = len(bufs)
     h, w = png_size(bufs[0])
+    for i in range(1, n):
+        hi, wi = png_size(bufs[i])
+        if (hi, wi) != (h, w):
+            who = names[i] if names is not None else f"buffer {i}"
+            raise ValueError(f"decode_batch: {who} is {wi} x {hi}, the batch started with {w} x {h} ({names[0] if names is not None else 'buffer 0'}); "
+                             "decode files of one size per call")
     out = torch.empty((n, h, w, channels), dtype=torch.uint8, pin_memory=pin and torch.cuda.is_available())
     ptrs = (ctypes.c_void_p * n)(*[b.ctypes.data for b in bufs])
     sizes = (ctypes.c_longlong * n)(*[b.size for b in bufs])
@@ -78,7 +85,7 @@ class ClassificationDataset:
     def load_batch(self, idxs, threads=8):
         paths = [self.samples[i][0] for i in idxs]
         labels = torch.tensor([self.samples[i][1] for i in idxs], dtype=torch.int64)
-        return decode_batch(read_files(paths), 3, threads), labels
+        return decode_batch(read_files(paths), 3, threads, names=paths), labels
 
     def __getitem__(self, idx):
         img, label = self.load_batch([idx], 1)
@@ -103,8 +110,9 @@ class SegmentationDataset:
         return len(self.pairs)
 
     def load_batch(self, idxs, threads=8):
-        imgs = decode_batch(read_files([self.pairs[i][0] for i in idxs]), 3, threads)
-        masks = decode_batch(read_files([self.pairs[i][1] for i in idxs]), 1, threads)
+        ip, mp = [self.pairs[i][0] for i in idxs], [self.pairs[i][1] for i in idxs]
+        imgs = decode_batch(read_files(ip), 3, threads, names=ip)
+        masks = decode_batch(read_files(mp), 1, threads, names=mp)
         return imgs, masks[..., 0]
 
     def __getitem__(self, idx):

@@ -64,7 +64,7 @@ class JointPipeline:
         decoded by native threads (utils/dataset.py) and resized / normalised on the GPU (utils/gpu_transforms.py) as ONE batch."""
         from utils.dataset import decode_batch, read_files
         from utils.gpu_transforms import SegBatchTransform
-        imgs = decode_batch(read_files(paths), 3, threads)
+        imgs = decode_batch(read_files(paths), 3, threads, names=list(paths))
         x = SegBatchTransform(size, train=False, device=self.device)(imgs.to(self.device, non_blocking=True))
         return self.process_batch(x)
 

@@ -54,3 +54,20 @@ def test_sample_lists_and_native_decode_match_pil(tmp_path):
         assert np.array_equal(mk[j].numpy(), np.array(Image.open(seg.pairs[i][1]).convert("L")))
     x, y = seg[2]                                           # transform=None: the reference's ToTensorV2 fallback (dataset.py:129-133)
     assert x.shape == (3, 299, 299) and y.shape == (1, 256, 256) and float(y.max()) == 1.0 and y.dtype == torch.float32
+
+
+def test_decode_batch_names_the_file_of_another_size(tmp_path):
+    """decode_batch decodes files of ONE size into one buffer; a stray file of another size is refused BEFORE decoding, by path
+    (it used to surface as 'image i failed' with no reason)."""
+    from utils.dataset import decode_batch, read_files
+    g = np.random.RandomState(3)
+    paths = []
+    for i, hw in enumerate([(40, 50), (40, 50), (41, 50)]):
+        p = str(tmp_path / f"im{i}.png")
+        Image.fromarray(g.randint(0, 256, hw).astype(np.uint8), "L").save(p)
+        paths.append(p)
+    assert decode_batch(read_files(paths[:2]), 3, 2, names=paths[:2]).shape == (2, 40, 50, 3)
+    with pytest.raises(ValueError, match=r"im2\.png is 50 x 41, the batch started with 50 x 40"):
+        decode_batch(read_files(paths), 3, 2, names=paths)
+    with pytest.raises(ValueError, match="buffer 2 is 50 x 41"):
+        decode_batch(read_files(paths), 1, 2)

@@ -145,6 +145,38 @@ def test_maxpool(dtype, k, s, p, hw):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("act", [0, 1])
+def test_bn_act_with_fused_maxpool_is_bit_identical_to_the_two_passes(dtype, act):
+    """mi355_bn_act_pool2 (BatchNorm apply + ReLU + the MaxPool2d(2, 2) of AttentionUNet.py:61,89-95 in one pass) against
+    mi355_bn_act followed by mi355_maxpool_fwd: activation and pooled tensor bit for bit, both written into channel slices of
+    wider buffers; and against torch on the CPU."""
+    n, c, h, w = 3, 40, 10, 12
+    g = torch.Generator().manual_seed(4 + act)
+    x = q(torch.randn(n, c, h, w, generator=g), dtype)
+    sc, sh = torch.randn(c, generator=g), torch.randn(c, generator=g)
+    code = DTYPE_CODE[dtype]
+    xd = to_nhwc(x, dtype)
+    es = xd.element_size()
+    outs = []
+    for fused in (0, 1):
+        y = torch.zeros(n, h, w, c + 8, dtype=dtype, device=DEV)
+        p = torch.zeros(n, h // 2, w // 2, c + 16, dtype=dtype, device=DEV)
+        if fused:
+            lib.mi355_bn_act_pool2(xd, c, dev(sc), dev(sh), y.data_ptr() + 8 * es, c + 8, p.data_ptr() + 16 * es, c + 16, n, h, w, c, act, code)
+        else:
+            lib.mi355_bn_act(xd, c, dev(sc), dev(sh), None, 0, None, None, None, 0, y.data_ptr() + 8 * es, c + 8, n * h * w, c, act, code)
+            lib.mi355_maxpool_fwd(y.data_ptr() + 8 * es, c + 8, p.data_ptr() + 16 * es, c + 16, n, h, w, c, 2, 2, 0, code)
+        torch.cuda.synchronize()
+        outs.append((y.cpu(), p.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ref = x * sc[None, :, None, None] + sh[None, :, None, None]
+    ref = F.relu(ref) if act else ref
+    assert rel_err(from_nhwc(outs[1][0][..., 8:]), ref) < TOL[dtype]
+    assert rel_err(from_nhwc(outs[1][1][..., 16:]), F.max_pool2d(q(ref, dtype), 2, 2)) < TOL[dtype]
+    assert float(outs[1][0][..., :8].abs().sum()) == 0 and float(outs[1][1][..., :16].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_upsample_bwd_add_relu(dtype):
     n, c, h, w = 2, 32, 5, 7
     g = torch.Generator().manual_seed(9)

@@ -106,6 +106,20 @@ def test_concat_is_free_and_slices_share_storage():
     assert len(gate) == 4 and all(l.args[6] == 2 * l.args[8] for l in gate)   # ldy == 2*C
 
 
+def test_maxpool_rides_in_the_batchnorm_apply_pass():
+    """AttentionUNet.py:61,89-95: the four MaxPool2d(2, 2) read the activation a BatchNorm apply pass has just written — the
+    plan emits ONE mi355_bn_act_pool2 per encoder level instead of mi355_bn_act + mi355_maxpool_fwd; the backward still sees
+    the pooling (mi355_maxpool_bwd) and Plan.acts still lists it (the kink replay of tests/test_gpu_kinks.py)."""
+    from models.segmentation_models.AttentionUNet import AttentionUNet
+    net = AttentionUNet().train()
+    net.engine.flatten()
+    plan = net.engine.plan_for((2, 3, 64, 64), True, True, torch.bfloat16)
+    names = [l.name for l in plan.fwd]
+    assert names.count("mi355_bn_act_pool2") == 4 and "mi355_maxpool_fwd" not in names
+    assert sum(l.name == "mi355_maxpool_bwd" for l in plan.bwd) == 4 and sum(a[0] == "pool" for a in plan.acts) == 4
+    plan.bind(0)                                   # ABI arity of the new entry point
+
+
 def test_no_cpu_fallback():
     from models.segmentation_models.AttentionUNet import AttentionUNet
     with pytest.raises(RuntimeError, match="no CPU fallback"):

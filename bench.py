@@ -353,16 +353,17 @@ def main():
                                   "avg_launch_ms": round(ms_ / n, 4), "share_of_plan_time": round(ms_ / total, 3)}
         # the kernels behind the dominant one (same measurement): the step is not one kernel
         also = []
-        for k2, (ms2, n2, fl2, nb2) in ranked[1:6]:
+        for k2, (ms2, n2, fl2, nb2) in ranked[1:7]:
+            t2, _ = pmc_traffic(k2)          # HBM bytes per launch from the same PMC file as the dominant kernel's (None: not in it)
+            extra = {"launches_per_step": n2 // 2, "share_of_plan_time": round(ms2 / total, 3), "avg_launch_ms": round(ms2 / n2, 4),
+                     "traffic": t2, "algorithmic_bytes_per_launch": int(nb2 / n2) if nb2 else None}
             if fl2:
                 a2 = fl2 / (ms2 * 1e-3) / 1e12
                 also.append({"kernel": k2, "bound": "mfma", "achieved": round(a2, 1), "unit": "TFLOP/s",
-                             "frac": round(a2 / PEAK_TFLOPS[args.dtype], 4), "launches_per_step": n2 // 2,
-                             "share_of_plan_time": round(ms2 / total, 3)})
+                             "frac": round(a2 / PEAK_TFLOPS[args.dtype], 4), **extra})
             elif nb2:
                 a2 = nb2 / (ms2 * 1e-3) / 1e9
-                also.append({"kernel": k2, "bound": "hbm", "achieved": round(a2, 1), "unit": "GB/s", "frac": round(a2 / 8000.0, 4),
-                             "launches_per_step": n2 // 2, "share_of_plan_time": round(ms2 / total, 3)})
+                also.append({"kernel": k2, "bound": "hbm", "achieved": round(a2, 1), "unit": "GB/s", "frac": round(a2 / 8000.0, 4), **extra})
         result["roofline"]["next_kernels"] = also
         result["roofline"]["plan_kernel_ms_per_step"] = round(total / 2, 3)
 

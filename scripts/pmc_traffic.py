@@ -32,13 +32,20 @@ def demangle(name):
     return f"{base}<{','.join(args)}>"
 
 
+# streaming kernels are templates over an Op type: bench.py tags them by their launcher
+OP_TAGS = (("BnBwdReduceOp", "mi355_bn_bwd_reduce"), ("BnBwdApplyOp", "mi355_bn_bwd_apply"), ("BnActOp", "mi355_bn_act"),
+           ("bn_act_pool2_kernel", "mi355_bn_act_pool2"), ("BnStatsOp", "mi355_bn_stats"))
+
+
 def per_kernel(pattern, counter):
     tot, cnt = collections.defaultdict(float), collections.Counter()
     for f in glob.glob(pattern, recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            k = re.sub(r"\(.*", "", demangle(r["Kernel_Name"])).replace("void ", "").strip()
+            raw = r["Kernel_Name"]
+            op = [t for o, t in OP_TAGS if o in raw]
+            k = op[0] if op else re.sub(r"\(.*", "", demangle(raw)).replace("void ", "").strip()
             k = k.replace("__hip_bfloat16", "bf16").replace("__bf16", "bf16").replace("_Float16", "f16").replace(" ", "")
             tot[k] += float(r["Counter_Value"])
             cnt[k] += 1
@@ -51,7 +58,7 @@ out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (
                  "--warmup 1 --no-cpu-baseline --no-profile), counters in KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md "
                  "(gfx950 reports 1/2 of wide coalesced reads)", "kernels": {}}
 for k in sorted(fetch, key=lambda k: -(2 * fetch[k] + write.get(k, 0))):
-    if "conv" not in k and "wgrad" not in k:
+    if "conv" not in k and "wgrad" not in k and not k.startswith("mi355_bn_"):
         continue
     f = 2 * fetch[k] * 1024 / nf[k] / 1e6
     w = write.get(k, 0) * 1024 / max(nw.get(k, 1), 1) / 1e6

@@ -56,6 +56,20 @@ def _build(name, dtype):
     return m.to(DEV), sd, kw
 
 
+# (median, maximum) deviation of the per-tensor gradient NORMS from the reference's, per model: twice what the HIP path measures on
+# these fixtures (printed by the test); two fp32 evaluations of a network with ReLU / max-pool kinks differ by this much whatever
+# the implementation — the CPU oracle with the GPU's masks replayed agrees to 1e-3 everywhere (tests/test_gpu_kinks.py)
+GRAD_NORM_BOUNDS = {   # measured (r03): median / max
+    "AttentionUNet": (1e-3, 8e-2),      # 3.6e-4 / 4.6e-2 (103 tensors; the maximum is one small tensor behind a handful of flipped masks)
+    "R2AttU_Net": (2e-3, 8e-2),         # 6.7e-4 / 6.1e-2
+    "R2U_Net": (1e-4, 4e-3),            # 1.6e-5 / 1.3e-3
+    "ResNet18": (1e-5, 2e-5),           # 1.0e-6 / 2.6e-6: no mask flips on this fixture, the kernels' fp32 rounding alone
+    "ResNet50": (2e-3, 3e-2),           # 5.9e-4 / 1.0e-2
+    "VGG16": (2e-6, 2e-6),              # 1.2e-7 / 2.1e-7
+    "VGG19": (2e-6, 3e-6),              # 4.3e-7 / 6.4e-7
+}
+
+
 @pytest.mark.parametrize("name", ["AttentionUNet", "R2AttU_Net", "R2U_Net", "ResNet18", "ResNet50", "VGG16", "VGG19"])
 def test_fp32_model_matches_reference_golden_and_oracle(name):
     from mi355 import nn as mnn, optim as moptim
@@ -92,7 +106,9 @@ def test_fp32_model_matches_reference_golden_and_oracle(name):
     gn = np.array([float(params[k].grad.double().norm()) for k in names])
     big = z["grad_norm"] > 1e-5 * z["grad_norm"].max()
     dev = np.abs(gn[big] / z["grad_norm"][big] - 1)
-    assert np.median(dev) <= 1e-2 and dev.max() <= 8e-2, (np.median(dev), dev.max())
+    print(f"golden gradient norms {name}: median deviation {np.median(dev):.2e}, max {dev.max():.2e} over {int(big.sum())} tensors")
+    med_tol, max_tol = GRAD_NORM_BOUNDS[name]
+    assert np.median(dev) <= med_tol and dev.max() <= max_tol, (np.median(dev), dev.max())
     # BN buffers after one train-mode forward
     msd = m.state_dict()
     for k, l2 in zip([str(s) for s in z["buffer_names"]], z["buffer_l2_after"]):

@@ -303,10 +303,12 @@ int mi355_normalize_u8(const uint8_t* src, int N, int H, int W, int C, const flo
                        float* out, mi355_stream_t s);
 
 /* ---- PNG files -> uint8 batch on the host (utils/dataset.py:55,101-102: PIL Image.open(path).convert("RGB" | "L")) ----------- */
-/* Header fields of a PNG held in memory.  MI355_ERR_UNSUPPORTED (fields still filled) for 16-bit samples / Adam7 interlacing. */
+/* Header fields of a PNG held in memory.  MI355_ERR_UNSUPPORTED (fields still filled) for an unknown interlace method or more
+ * than 32768 pixels per side. */
 int mi355_png_info(const uint8_t* file, long long nbytes, int* W, int* H, int* color_type, int* bit_depth);
 /* out[H][W][channels] uint8 = what PIL yields for .convert("RGB") (channels = 3) or .convert("L") (channels = 1): gray replicated,
- * alpha dropped, palette looked up, 1/2/4-bit gray scaled to 0..255, RGB -> L by (19595 R + 38470 G + 7471 B + 0x8000) >> 16. */
+ * alpha dropped, palette looked up, 1/2/4-bit gray scaled to 0..255, RGB -> L by (19595 R + 38470 G + 7471 B + 0x8000) >> 16;
+ * 16-bit RGB / RGBA / gray+alpha keep the high byte, 16-bit gray (PIL mode I;16) SATURATES at 255; Adam7-interlaced files too. */
 int mi355_png_decode(const uint8_t* file, long long nbytes, int channels, uint8_t* out, long long out_bytes);
 /* n files of one size W x H into out + i * stride (a pinned host batch), decoded by `threads` native threads. */
 int mi355_png_decode_batch(const uint8_t* const* files, const long long* nbytes, int n, int channels, uint8_t* out,

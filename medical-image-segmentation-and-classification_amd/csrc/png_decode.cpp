@@ -3,11 +3,12 @@
 // DataLoader worker processes.  Here a batch of PNG files is decoded by a pool of native threads straight into ONE pinned
 // uint8 [N][H][W][C] buffer that the GPU transforms (input_pipeline.hip) consume; no Python object per sample.
 //
-// Scope = what PIL's PngImagePlugin yields for the dataset's files and their close relatives: non-interlaced, 8-bit gray /
-// gray+alpha / RGB / RGBA, palette images of 1-8 bits, gray of 1, 2, 4 bits; tRNS is ignored by convert("RGB" / "L").
-// 16-bit samples and Adam7 interlacing return MI355_ERR_UNSUPPORTED (PIL maps 16-bit gray through mode I;16 with its own
-// clipping rule; neither occurs in the COVID-19 Radiography files).  DEFLATE is zlib's inflate; chunk walk, un-filtering (PNG
-// filter types 0-4) and the mode conversions are below.  convert("L") uses PIL's ITU-R 601-2 integer luma
+// Scope = what PIL's PngImagePlugin yields for every colour type / bit depth of the PNG specification: gray of 1, 2, 4, 8 and
+// 16 bits, gray+alpha / RGB / RGBA of 8 and 16 bits, palette images of 1-8 bits, non-interlaced and Adam7-interlaced; tRNS is
+// ignored by convert("RGB" / "L").  16-bit samples follow PIL: colour types 2, 4, 6 are opened through the "...;16B" raw modes,
+// which keep the HIGH byte; 16-bit gray is opened as mode I;16, whose conversion to "L" / "RGB" SATURATES (value > 255 -> 255,
+// Convert.c I16L_L) instead of scaling.  DEFLATE is zlib's inflate; chunk walk, un-filtering (PNG filter types 0-4, per
+// interlace pass) and the mode conversions are below.  convert("L") uses PIL's ITU-R 601-2 integer luma
 // (19595 R + 38470 G + 7471 B + 0x8000) >> 16.
 #include <stdint.h>
 #include <stdlib.h>
@@ -86,11 +87,11 @@ int walk(const uint8_t* f, long long n, PngHead& hd, const uint8_t*& plte, int& 
     mi355_set_error("png: %ux%u exceeds the decoder's 32768 x 32768 limit", hd.w, hd.h);
     return MI355_ERR_UNSUPPORTED;
   }
-  const bool depth_ok = (hd.color == 0 && (hd.depth == 1 || hd.depth == 2 || hd.depth == 4 || hd.depth == 8)) ||
+  const bool depth_ok = (hd.color == 0 && (hd.depth == 1 || hd.depth == 2 || hd.depth == 4 || hd.depth == 8 || hd.depth == 16)) ||
                         (hd.color == 3 && (hd.depth == 1 || hd.depth == 2 || hd.depth == 4 || hd.depth == 8)) ||
-                        ((hd.color == 2 || hd.color == 4 || hd.color == 6) && hd.depth == 8);
-  if (hd.depth == 16 || hd.interlace != 0) {
-    mi355_set_error("png: %s is not supported by the native decoder", hd.depth == 16 ? "16-bit samples" : "Adam7 interlacing");
+                        ((hd.color == 2 || hd.color == 4 || hd.color == 6) && (hd.depth == 8 || hd.depth == 16));
+  if (hd.interlace > 1) {
+    mi355_set_error("png: unknown interlace method %d", hd.interlace);
     return MI355_ERR_UNSUPPORTED;
   }
   if (!depth_ok) {
@@ -131,9 +132,23 @@ int decode_one(const uint8_t* f, long long n, int want, uint8_t* out, long long 
     return MI355_ERR_ARG;
   }
   const int bits = hd.depth * hd.channels();
-  const size_t stride = ((size_t)hd.w * bits + 7) / 8;
   const int bpp = bits >= 8 ? bits / 8 : 1;
-  std::vector<uint8_t> raw((stride + 1) * hd.h);
+  // interlace passes: (x0, y0, dx, dy); a non-interlaced image is one pass over every pixel
+  static const int kAdam7[7][4] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+  static const int kWhole[1][4] = {{0, 0, 1, 1}};
+  const int (*passes)[4] = hd.interlace ? kAdam7 : kWhole;
+  const int npass = hd.interlace ? 7 : 1;
+  auto pass_dim = [&](int p, uint32_t& pw, uint32_t& ph) {
+    pw = hd.w > (uint32_t)passes[p][0] ? (hd.w - passes[p][0] + passes[p][2] - 1) / passes[p][2] : 0;
+    ph = hd.h > (uint32_t)passes[p][1] ? (hd.h - passes[p][1] + passes[p][3] - 1) / passes[p][3] : 0;
+  };
+  size_t total = 0;
+  for (int p = 0; p < npass; ++p) {
+    uint32_t pw, ph;
+    pass_dim(p, pw, ph);
+    if (pw && ph) total += (((size_t)pw * bits + 7) / 8 + 1) * ph;      // (an empty pass contributes no bytes, not even filter bytes)
+  }
+  std::vector<uint8_t> raw(total);
   z_stream zs;
   memset(&zs, 0, sizeof(zs));
   if (inflateInit(&zs) != Z_OK) {
@@ -155,66 +170,77 @@ int decode_one(const uint8_t* f, long long n, int want, uint8_t* out, long long 
     mi355_set_error("png: corrupt or truncated image data (zlib %d)", zr);
     return MI355_ERR_ARG;
   }
-  // un-filter in place (row r: filter byte + stride bytes)
-  for (uint32_t y = 0; y < hd.h; ++y) {
-    uint8_t* row = raw.data() + (size_t)y * (stride + 1);
-    const int ft = row[0];
-    uint8_t* cur = row + 1;
-    const uint8_t* up = y ? row - stride : nullptr;      // previous row's data (its filter byte sits in front of it)
-    switch (ft) {
-      case 0: break;
-      case 1:
-        for (size_t i = bpp; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + cur[i - bpp]);
-        break;
-      case 2:
-        if (up) for (size_t i = 0; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + up[i]);
-        break;
-      case 3:
-        for (size_t i = 0; i < stride; ++i) {
-          const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0;
-          cur[i] = (uint8_t)(cur[i] + ((a + b) >> 1));
-        }
-        break;
-      case 4:
-        for (size_t i = 0; i < stride; ++i) {
-          const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= (size_t)bpp) ? up[i - bpp] : 0;
-          cur[i] = (uint8_t)(cur[i] + paeth(a, b, c));
-        }
-        break;
-      default:
-        mi355_set_error("png: unknown filter type %d", ft);
-        return MI355_ERR_ARG;
-    }
-  }
-  // mode conversion (PIL: Image.open(...).convert("RGB" | "L"))
   const int scale = hd.depth == 1 ? 255 : hd.depth == 2 ? 85 : hd.depth == 4 ? 17 : 1;
-  for (uint32_t y = 0; y < hd.h; ++y) {
-    const uint8_t* src = raw.data() + (size_t)y * (stride + 1) + 1;
-    uint8_t* dst = out + (size_t)y * hd.w * want;
-    for (uint32_t x = 0; x < hd.w; ++x) {
-      int r, g, b;
-      if (hd.color == 0 || hd.color == 3) {
-        int v;
-        if (hd.depth == 8) v = src[x];
-        else {
-          const int per = 8 / hd.depth, sh = (per - 1 - (int)(x % per)) * hd.depth;
-          v = (src[x / per] >> sh) & ((1 << hd.depth) - 1);
-        }
-        if (hd.color == 3) {
-          if (v < nplte) { r = plte[3 * v]; g = plte[3 * v + 1]; b = plte[3 * v + 2]; }
-          else r = g = b = 0;
-        } else {
-          r = g = b = v * scale;
-        }
-      } else if (hd.color == 4) {
-        r = g = b = src[2 * x];
-      } else {
-        const int c = hd.color == 2 ? 3 : 4;
-        r = src[c * x]; g = src[c * x + 1]; b = src[c * x + 2];
+  const int sb = hd.depth == 16 ? 2 : 1;              // bytes per sample (16-bit: big-endian, the high byte first)
+  uint8_t* base = raw.data();
+  for (int p = 0; p < npass; ++p) {
+    uint32_t pw, ph;
+    pass_dim(p, pw, ph);
+    if (!pw || !ph) continue;
+    const size_t stride = ((size_t)pw * bits + 7) / 8;
+    // un-filter the pass in place (row r: filter byte + stride bytes)
+    for (uint32_t y = 0; y < ph; ++y) {
+      uint8_t* row = base + (size_t)y * (stride + 1);
+      const int ft = row[0];
+      uint8_t* cur = row + 1;
+      const uint8_t* up = y ? row - stride : nullptr;      // previous row's data (its filter byte sits in front of it)
+      switch (ft) {
+        case 0: break;
+        case 1:
+          for (size_t i = bpp; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + cur[i - bpp]);
+          break;
+        case 2:
+          if (up) for (size_t i = 0; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + up[i]);
+          break;
+        case 3:
+          for (size_t i = 0; i < stride; ++i) {
+            const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0;
+            cur[i] = (uint8_t)(cur[i] + ((a + b) >> 1));
+          }
+          break;
+        case 4:
+          for (size_t i = 0; i < stride; ++i) {
+            const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= (size_t)bpp) ? up[i - bpp] : 0;
+            cur[i] = (uint8_t)(cur[i] + paeth(a, b, c));
+          }
+          break;
+        default:
+          mi355_set_error("png: unknown filter type %d", ft);
+          return MI355_ERR_ARG;
       }
-      if (want == 3) { dst[3 * x] = (uint8_t)r; dst[3 * x + 1] = (uint8_t)g; dst[3 * x + 2] = (uint8_t)b; }
-      else dst[x] = (hd.color == 0 || hd.color == 4) ? (uint8_t)r : luma(r, g, b);
     }
+    // mode conversion (PIL: Image.open(...).convert("RGB" | "L")), scattered to the pass's pixel grid
+    for (uint32_t y = 0; y < ph; ++y) {
+      const uint8_t* src = base + (size_t)y * (stride + 1) + 1;
+      uint8_t* drow = out + ((size_t)(passes[p][1] + y * passes[p][3]) * hd.w) * want;
+      for (uint32_t x = 0; x < pw; ++x) {
+        int r, g, b;
+        if (hd.color == 0 || hd.color == 3) {
+          int v;
+          if (hd.depth == 16) v = src[2 * x] ? 255 : src[2 * x + 1];      // mode I;16 -> "L" / "RGB": saturates (PIL Convert.c)
+          else if (hd.depth == 8) v = src[x];
+          else {
+            const int per = 8 / hd.depth, sh = (per - 1 - (int)(x % per)) * hd.depth;
+            v = (src[x / per] >> sh) & ((1 << hd.depth) - 1);
+          }
+          if (hd.color == 3) {
+            if (v < nplte) { r = plte[3 * v]; g = plte[3 * v + 1]; b = plte[3 * v + 2]; }
+            else r = g = b = 0;
+          } else {
+            r = g = b = v * scale;
+          }
+        } else if (hd.color == 4) {
+          r = g = b = src[2 * sb * x];                  // (16-bit: the high byte, raw mode LA;16B)
+        } else {
+          const int c = (hd.color == 2 ? 3 : 4) * sb;
+          r = src[c * x]; g = src[c * x + sb]; b = src[c * x + 2 * sb];
+        }
+        uint8_t* dst = drow + (size_t)(passes[p][0] + x * passes[p][2]) * want;
+        if (want == 3) { dst[0] = (uint8_t)r; dst[1] = (uint8_t)g; dst[2] = (uint8_t)b; }
+        else dst[0] = (hd.color == 0 || hd.color == 4) ? (uint8_t)r : luma(r, g, b);
+      }
+    }
+    base += (stride + 1) * ph;
   }
   return MI355_OK;
 }

@@ -501,9 +501,84 @@ def png_fixture():
             rec[f"{name}/rgb"] = np.array(ref.convert("RGB"))
             rec[f"{name}/l"] = np.array(ref.convert("L"))
             names.append(name)
-    bio = io.BytesIO()
-    Image.fromarray((xray[:32, :32].astype(np.uint16) * 257), "I;16").save(bio, format="PNG")
-    rec["gray16_unsupported/png"] = np.frombuffer(bio.getvalue(), dtype=np.uint8)
+    # ---- streams PIL cannot WRITE (16-bit colour, Adam7) but reads: assembled here by hand, every PNG filter type in use, and
+    # decoded by PIL for the expected arrays.  16-bit gray opens as mode I;16, whose convert("L" / "RGB") saturates at 255.
+    import struct
+    import zlib
+
+    def paeth(a, b, c):
+        p = a + b - c
+        pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+        return a if pa <= pb and pa <= pc else (b if pb <= pc else c)
+
+    def filt(ft, row, prev, bpp):
+        out = bytearray(len(row))
+        for i, v in enumerate(row):
+            a = row[i - bpp] if i >= bpp else 0
+            b = prev[i] if prev is not None else 0
+            c = prev[i - bpp] if prev is not None and i >= bpp else 0
+            pred = (0, a, b, (a + b) >> 1, paeth(a, b, c))[ft]
+            out[i] = (v - pred) & 255
+        return bytes(out)
+
+    def pack_rows(samples, depth):
+        """samples: uint array [h][w * channels] -> list of packed row byte strings"""
+        rows = []
+        for r in samples:
+            if depth == 16:
+                rows.append(r.astype(">u2").tobytes())
+            elif depth == 8:
+                rows.append(r.astype(np.uint8).tobytes())
+            else:
+                bits = np.unpackbits(r.astype(np.uint8)[:, None], axis=1)[:, 8 - depth:].reshape(-1)
+                rows.append(np.packbits(bits).tobytes())
+        return rows
+
+    def make_png(samples, color, depth, interlace, plte=None):
+        """samples [h][w][channels] unsigned ints -> PNG byte stream (filter type cycles 0..4 over the rows of every pass)"""
+        h, w, ch = samples.shape
+        bpp = max(1, depth * ch // 8)
+        passes = [(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)] if interlace else [(0, 0, 1, 1)]
+        raw, k = b"", 0
+        for x0, y0, dx, dy in passes:
+            sub = samples[y0::dy, x0::dx]
+            if sub.shape[0] == 0 or sub.shape[1] == 0:
+                continue
+            prev = None
+            for row in pack_rows(sub.reshape(sub.shape[0], -1), depth):
+                ft = k % 5
+                raw += bytes([ft]) + filt(ft, row, prev, bpp)
+                prev, k = row, k + 1
+
+        def chunk(t, d):
+            return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+        body = chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, color, 0, 0, 1 if interlace else 0))
+        if plte is not None:
+            body += chunk(b"PLTE", plte.astype(np.uint8).tobytes())
+        z = zlib.compress(raw, 6)
+        body += chunk(b"IDAT", z[:len(z) // 2]) + chunk(b"IDAT", z[len(z) // 2:])      # (two IDAT chunks: the payload is their concatenation)
+        return b"\x89PNG\r\n\x1a\n" + body + chunk(b"IEND", b"")
+
+    u16 = lambda *s_: g.randint(0, 65536, s_)
+    low16 = np.where(g.rand(9, 13, 1) < 0.5, g.randint(0, 256, (9, 13, 1)), u16(9, 13, 1))      # half the pixels below 256: not saturated
+    hand = {
+        "gray16": make_png(low16, 0, 16, 0), "gray16_adam7": make_png(low16, 0, 16, 1),
+        "rgb16": make_png(u16(7, 11, 3), 2, 16, 0), "rgb16_adam7": make_png(u16(7, 11, 3), 2, 16, 1),
+        "gray_alpha16": make_png(u16(6, 9, 2), 4, 16, 0), "rgba16_adam7": make_png(u16(10, 9, 4), 6, 16, 1),
+        "gray8_adam7": make_png(g.randint(0, 256, (33, 29, 1)), 0, 8, 1), "rgb8_adam7": make_png(g.randint(0, 256, (17, 40, 3)), 2, 8, 1),
+        "rgba8_adam7_tiny": make_png(g.randint(0, 256, (3, 2, 4)), 6, 8, 1),                     # several empty passes
+        "gray1_adam7": make_png(g.randint(0, 2, (19, 23, 1)), 0, 1, 1), "gray4_adam7": make_png(g.randint(0, 16, (12, 21, 1)), 0, 4, 1),
+        "palette2_adam7": make_png(g.randint(0, 4, (14, 15, 1)), 3, 2, 1, plte=g.randint(0, 256, (4, 3))),
+        "palette8_adam7": make_png(g.randint(0, 200, (16, 16, 1)), 3, 8, 1, plte=g.randint(0, 256, (200, 3))),
+        "one_pixel_adam7": make_png(g.randint(0, 256, (1, 1, 3)), 2, 8, 1),
+    }
+    for name, data in hand.items():
+        ref = Image.open(io.BytesIO(data))
+        ref.load()
+        rec[f"{name}/png"] = np.frombuffer(data, dtype=np.uint8)
+        rec[f"{name}/rgb"] = np.array(ref.convert("RGB"))
+        rec[f"{name}/l"] = np.array(Image.open(io.BytesIO(data)).convert("L"))
+        names.append(name)
     rec["names"] = np.array(names)
     np.savez_compressed(os.path.join(OUT, "png_cases.npz"), **rec)
     print("png_cases:", len(names), "streams, pillow", PIL.__version__)

@@ -9,12 +9,12 @@
 // is 96 MFMAs = 1536 pipe cycles, twice the 64-channel kernel's, while a load phase carries 24 fragment reads and 3-6 DMA
 // issues — it now fits under the other half's matrix phase.
 //
-//   LDS         : 2 patch buffers x 39 KiB + 3 weight stages x 24 KiB = 150 KiB -> one workgroup per CU
+//   LDS         : 2 patch buffers x 41 KiB (36-pixel pitch) + 3 weight stages x 24 KiB = 154 KiB -> one workgroup per CU
 //   DMA         : every wave brings rows [16 wave, +16) of the three slabs of the stage two steps ahead (3 pieces per step) and
-//                 3 / 2 / 0 of its five pieces of the NEXT slab's patch in the steps pw = 0 / 1 / 2 of a slab (buffer (c+1) % 2,
-//                 last read during slab c-1).  Issue order per step: stage pieces, then patch pieces; the counted wait at the end
-//                 of a wave's (2s+1)-phase leaves in flight exactly what was issued after the youngest piece the next load phase
-//                 needs: 6 / 8 / 3 instructions for pw = 0 / 1 / 2
+//                 2 / 2 / 1 of its five pieces of the NEXT slab's patch in the steps pw = 0 / 1 / 2 of a slab (one in R(s, 0), the
+//                 other with the stage in R(s, 1): PA / PB below; buffer (c+1) % 2, last read during slab c-1).  The counted wait at
+//                 the end of a step leaves in flight exactly what was issued after the youngest piece the next load phase needs:
+//                 5 / 6 / 3 instructions for pw = 0 / 1 / 2 (wait_w)
 //   registers   : 128 accumulators + 12 + 12 fragments (96) -> launch bound 512 threads = 256 registers per lane
 // Selected for Co % 128 == 0 and deep reductions only (one workgroup per CU exposes each tile's prologue and epilogue).
 #pragma once

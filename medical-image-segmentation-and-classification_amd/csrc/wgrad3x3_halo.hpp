@@ -6,8 +6,8 @@
 // 16x16, 144 accumulator registers per lane) and walks 32-pixel row segments of the image: per step it needs ONE
 // new dY row segment and ONE new X row segment (a rolling window with a 1-pixel halo serves the nine shifted
 // reads), so dY and X are streamed from L2 once per 36 MFMAs per wave — 9x less L2->LDS traffic than the per-tap
-// split-K kernel (which is L2-bound for C <= 128).  Rows arrive by LDS-DMA (asm-issued, counted vmcnt, three rows
-// ahead); fragments are fetched with the hardware transpose read ds_read_b64_tr_b16 from [pixel][64 ch] row images.
+// split-K kernel (which is L2-bound for C <= 128).  Rows arrive by LDS-DMA (asm-issued, counted vmcnt, WG3_PF = 7 rows
+// ahead into eight-row rings); fragments are fetched with the hardware transpose read ds_read_b64_tr_b16 from [pixel][64 ch] row images.
 // (nearest x2 up-sampling of X is folded into the row gather.)
 #pragma once
 #include <type_traits>

@@ -77,7 +77,7 @@ int mi355_pack_conv_weights_batched(const int64_t* table, int n, int fields /* =
  * bit 1 applies max(0, .) to conv + bias first (nn.ReLU fused into the epilogue: VGG.py:9-41, and eval-mode
  * Conv -> BN -> ReLU with the BN folded into weights and bias), bit 2 sums every 2x2 group of output pixels into a
  * half-resolution `out` [N][Ho/2][Wo/2] (the gradient of the nearest x2 up-sampling that the forward conv folds into
- * its gather, AttentionUNet.py:19; halo kernels only: mi355_conv2d_igemm_variant(...) in {2, 3, 5, 6, 7}).
+ * its gather, AttentionUNet.py:19; halo kernels only: mi355_conv2d_igemm_variant(...) in {2, 3, 5, 6, 7, 8}).
  * bf16 / fp16 dispatch: 3x3/s1/p1 with Co % 64 == 0 on images divisible by an 8x32 or 16x16 tile ->
  * conv3x3_halo_rw_kernel (halo patch in LDS by LDS-DMA, patch-row register window); 1x1/s1 with (Ci, Co) among
  * 32/64/128-channel pairs (the attention-gate projections, AttentionUNet.py:33-45) -> conv1x1_stream_kernel (weights in
@@ -94,7 +94,8 @@ int mi355_conv2d_igemm(const void* in, const void* wk, const float* bias, void* 
  * per CU, so the launcher falls back to variant 2 for a batch whose grid would leave more than a fifth of the last round of
  * workgroups empty; mi355_conv2d_igemm_stat_rows, which knows N, follows the launcher); 7 the weight-stationary persistent
  * kernel (3x3/s1/p1, Ci == 64, Co % 64 == 0, image divisible by 8 x 32: the 64-channel layers of every U-Net level,
- * AttentionUNet.py:62-63,82, R2AttU_Net.py:36-39; the launcher falls back to variant 2 below two tiles per workgroup). */
+ * AttentionUNet.py:62-63,82, R2AttU_Net.py:36-39; the launcher falls back to variant 2 below two tiles per workgroup); 8 its
+ * Ci == 128 instantiation (4 x 32-pixel tiles: AttentionUNet.py:65-66,78-79,81). */
 int mi355_conv2d_igemm_variant(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int mul, int kmul, int off,
                                int div, int up, int dtype);
 /* ... and the variant the launcher actually runs for a batch of N images (the batch-dependent fall-backs applied). */

@@ -507,7 +507,7 @@ static int launch_dma(const ConvArgs& a, hipStream_t s) {
 #include "conv3x3_halo.hpp"
 #include "conv3x3_halo_pp.hpp"
 #include "conv3x3_halo_pp128.hpp"
-#include "conv3x3_ws64.hpp"
+#include "conv3x3_ws.hpp"
 #include "conv1x1_stream.hpp"
 
 template <typename T, int BN, int BK>
@@ -525,7 +525,7 @@ static int launch_bn(const ConvArgs& a, hipStream_t s) {
   return launch<T, 32, BK>(a, s);
 }
 
-enum IgemmVariant { IG_GENERIC = 0, IG_DMA, IG_HALO_8x32, IG_HALO_16x16, IG_STREAM1x1, IG_HALO_PP, IG_HALO_PP128, IG_WS64 };
+enum IgemmVariant { IG_GENERIC = 0, IG_DMA, IG_HALO_8x32, IG_HALO_16x16, IG_STREAM1x1, IG_HALO_PP, IG_HALO_PP128, IG_WS64, IG_WS128 };
 
 // ONE place that decides which kernel serves a shape (also used by the statistics-row query).
 static IgemmVariant pick_variant(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int mul, int kmul, int off,
@@ -550,9 +550,13 @@ static IgemmVariant pick_variant(int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
     static const int pp128 = getenv("MI355_HALO_PP128") ? atoi(getenv("MI355_HALO_PP128")) : 1;
     static const int pp128_min_ci = getenv("MI355_HALO_PP128_MINCI") ? atoi(getenv("MI355_HALO_PP128_MINCI")) : 256;
     if (pp128 && Co % 128 == 0 && Ci % 64 == 0 && Ci >= pp128_min_ci && Wo % 32 == 0 && Ho % 16 == 0) return IG_HALO_PP128;
-    // Ci = 64: weights stationary in registers, persistent workgroups (conv3x3_ws64.hpp); MI355_WS64=0 switches it off (A/B)
+    // Ci = 64 / 128: weights stationary in registers, persistent workgroups (conv3x3_ws.hpp); MI355_WS64=0 / MI355_WS128=0 switch
+    // them off (A/B)
     static const int ws64 = getenv("MI355_WS64") ? atoi(getenv("MI355_WS64")) : 1;
-    if (ws64 && ws64_shape(1, Hi, Wi, Ci, Ho, Wo, Co)) return IG_WS64;
+    static const int ws128 = getenv("MI355_WS128") ? atoi(getenv("MI355_WS128")) : 1;
+    const int ws_rows = ws_tile_rows(Ci, Ho, Wo, Co);
+    if (ws64 && ws_rows == 8) return IG_WS64;
+    if (ws128 && ws_rows == 4) return IG_WS128;
     if (Wo % 32 == 0 && Ho % 8 == 0) return IG_HALO_8x32;
     if (Wo % 16 == 0 && Ho % 16 == 0) return IG_HALO_16x16;
   }
@@ -578,10 +582,15 @@ static IgemmVariant resolve_variant(IgemmVariant v, int N, int Ho, int Wo, int C
   // the weight-stationary kernel is persistent (2 workgroups per CU): it wants at least two tiles per workgroup to amortise
   // its weight load, else the 4-wave kernel with its four-times finer grid
   // (MI355_WS64_MIN_TILES lowers the threshold: the parity tests run it on small shapes, one tile per workgroup included)
-  if (v == IG_WS64) {
+  if (v == IG_WS64 || v == IG_WS128) {
     static const long long min_tiles = getenv("MI355_WS64_MIN_TILES") ? atoll(getenv("MI355_WS64_MIN_TILES")) : 4ll * device_cus();
-    const long long S = (long long)N * (Ho / 8) * (Wo / 32);
-    return S >= 8 && S * (Co / 64) >= min_tiles ? IG_WS64 : IG_HALO_8x32;
+    const int th = v == IG_WS64 ? 8 : 4;
+    const long long S = (long long)N * (Ho / th) * (Wo / 32);
+    // (the 128-channel instantiation loads twice the weights per workgroup for tiles half as tall: measured per layer it wins
+    //  from 16 tiles per workgroup up — 128² x 128 -> 128 / 256, 256² x 128 -> 64: +3 ... +10 % — and loses 1-6 % at 8 —
+    //  64² x 128 -> 256, 128² x 128 -> 64, batch-16 layers — so its threshold is 12 tiles per workgroup = 24 x CUs)
+    if (S >= 8 && S * (Co / 64) >= min_tiles * (v == IG_WS128 ? 6 : 1)) return v;
+    return Ho % 8 == 0 ? IG_HALO_8x32 : (Ho % 16 == 0 && Wo % 16 == 0 ? IG_HALO_16x16 : IG_DMA);
   }
   if (v != IG_HALO_PP128) return v;
   const int cus = device_cus();
@@ -591,7 +600,7 @@ static IgemmVariant resolve_variant(IgemmVariant v, int N, int Ho, int Wo, int C
 }
 
 static bool halo_family(IgemmVariant v) {
-  return v == IG_HALO_8x32 || v == IG_HALO_16x16 || v == IG_HALO_PP || v == IG_HALO_PP128 || v == IG_WS64;
+  return v == IG_HALO_8x32 || v == IG_HALO_16x16 || v == IG_HALO_PP || v == IG_HALO_PP128 || v == IG_WS64 || v == IG_WS128;
 }
 static bool image_fits_descriptor(int Hi, int Wi, int ldi, int esz) { return (long long)Hi * Wi * ldi * esz < (1ll << 31); }
 static IgemmVariant final_variant(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int mul, int kmul, int off,
@@ -615,6 +624,7 @@ extern "C" int mi355_conv2d_igemm_stat_rows(int N, int Hi, int Wi, int Ci, int H
   switch (final_variant(N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up, dtype)) {
     case IG_HALO_PP:
     case IG_HALO_PP128: return N * (Ho / 16) * (Wo / 32);
+    case IG_WS128: return N * (Ho / 4) * (Wo / 32);
     case IG_WS64:
     case IG_HALO_8x32: return N * (Ho / 8) * (Wo / 32);
     case IG_HALO_16x16: return N * (Ho / 16) * (Wo / 16);
@@ -660,7 +670,7 @@ extern "C" int mi355_conv2d_igemm(const void* in, const void* wk, const float* b
   a.accumulate = accumulate & 1;
   a.relu = (accumulate >> 1) & 1;
   a.pool2 = (accumulate >> 2) & 1;
-  MI355_CHECK_ARG(!a.pool2 || ((v == IG_HALO_8x32 || v == IG_HALO_16x16 || v == IG_HALO_PP || v == IG_HALO_PP128 || v == IG_WS64) && !stats),
+  MI355_CHECK_ARG(!a.pool2 || ((v == IG_HALO_8x32 || v == IG_HALO_16x16 || v == IG_HALO_PP || v == IG_HALO_PP128 || v == IG_WS64 || v == IG_WS128) && !stats),
                   "conv2d_igemm: the 2x2-sum epilogue exists for the halo kernel only (mi355_conv2d_igemm_variant >= 2)");
   a.stats = stats;
   a.M = N * Ho * Wo;
@@ -676,7 +686,8 @@ extern "C" int mi355_conv2d_igemm(const void* in, const void* wk, const float* b
       switch (v) {
         case IG_HALO_PP: return launch_halo_pp<T>(a, st);
         case IG_HALO_PP128: return launch_halo_pp128<T>(a, st);
-        case IG_WS64: return launch_ws64<T>(a, st, device_cus());
+        case IG_WS64: return launch_ws<T, 64, 8>(a, st, device_cus());
+        case IG_WS128: return launch_ws<T, 128, 4>(a, st, device_cus());
         case IG_HALO_8x32: return launch_halo_rw<T, 8, 32>(a, st);
         case IG_HALO_16x16: return launch_halo_rw<T, 16, 16>(a, st);
         case IG_STREAM1x1: return launch_stream1x1<T>(a, st);

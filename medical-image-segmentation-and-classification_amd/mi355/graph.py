@@ -531,7 +531,7 @@ class Builder:
                     acc = self.acc_flag(x)
                     xg = self.grad_of(x)
                     tag = self.igemm_tag(x.N, Ho, Wo, Co, 2 * x.H, 2 * x.W, x.C, k, 1, -1, p, s, 0)
-                    if lib.mi355_conv2d_igemm_variant(Ho, Wo, Co, 2 * x.H, 2 * x.W, x.C, k, k, 1, -1, p, s, 0, self.code) in (2, 3, 5, 6, 7):
+                    if lib.mi355_conv2d_igemm_variant(Ho, Wo, Co, 2 * x.H, 2 * x.W, x.C, k, k, 1, -1, p, s, 0, self.code) in (2, 3, 5, 6, 7, 8):
                         # the data gradient lives on the up-sampled grid; its 2x2 sums go straight to the half-resolution
                         # gradient in the kernel epilogue (no full-resolution temporary, no separate pass)
                         self.bwd.append(Launch("mi355_conv2d_igemm", dy, wb, None, xg, x.N, Ho, Wo, Co, dy.ld, 2 * x.H, 2 * x.W,
@@ -580,7 +580,7 @@ class Builder:
                 return "conv_igemm_dma_kernel<128,64,2>" if k64 else "conv_igemm_dma_kernel<128,32,3>"
             return "conv_igemm_dma_kernel<64,32,3>" if bn == 64 else "conv_igemm_dma_kernel<32,64,3>"
         return {2: "conv3x3_halo_rw_kernel<8,32>", 3: "conv3x3_halo_rw_kernel<16,16>", 4: f"conv1x1_stream_kernel<{ci},{co}>",
-                5: "conv3x3_halo_pp_kernel", 6: "conv3x3_halo_pp128_kernel", 7: "conv3x3_ws64_kernel"}[v]
+                5: "conv3x3_halo_pp_kernel", 6: "conv3x3_halo_pp128_kernel", 7: "conv3x3_ws_kernel<64,8>", 8: "conv3x3_ws_kernel<128,4>"}[v]
 
     def wgrad_tag(self, co, ci, k=1, s=1, Ho=0, Wo=0):
         t = "f32" if self.dtype == torch.float32 else "bf16"       # (the fp16 build runs the same variants as bf16)

@@ -63,7 +63,7 @@ for k in sorted(fetch, key=lambda k: -(2 * fetch[k] + write.get(k, 0))):
     f = 2 * fetch[k] * 1024 / nf[k] / 1e6
     w = write.get(k, 0) * 1024 / max(nw.get(k, 1), 1) / 1e6
     # bench.py tags drop the element type of the templated kernels
-    tag = re.sub(r"<bf16,|<f16,", "<", k) if ("halo" in k or "dma" in k or "stream" in k) else k
+    tag = re.sub(r"<bf16,|<f16,", "<", k) if ("halo" in k or "dma" in k or "stream" in k or "ws_kernel" in k) else k
     tag = tag.replace("<bf16>", "").replace("<f16>", "")
     if tag.startswith("wgrad3x3_halo_kernel"):      # (both W16 instantiations of the nine-tap weight gradient: one bench tag)
         tag = "wgrad3x3_halo_kernel"

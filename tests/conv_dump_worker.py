@@ -24,7 +24,9 @@ CASES = [  # N, Ci, H, W, Co, k, up          (halo 8x32 / 16x16 / ping-pong-elig
 # test_weight_stationary_kernel_is_bit_identical_to_the_halo_kernel under MI355_WS64=0 and under MI355_WS64_MIN_TILES=8:
 # uneven tile ranges per workgroup (18 tiles on 16 groups), one / two / three channel tiles, fused up-sampling, 2x2-sum epilogue
 WS64_CASES = [(3, 64, 24, 64, 64, 3, 0), (2, 64, 32, 32, 128, 3, 0), (5, 64, 16, 96, 192, 3, 0), (2, 64, 16, 32, 64, 3, 1),
-              (4, 128, 24, 32, 64, 3, 0), (9, 64, 8, 32, 64, 3, 0)]
+              (4, 128, 24, 32, 64, 3, 0), (9, 64, 8, 32, 64, 3, 0),
+              # Ci = 128 instantiation (4 x 32-pixel tiles, four slabs): uneven ranges, 1 / 2 channel tiles, H % 8 == 4, up-sampling
+              (3, 128, 24, 64, 128, 3, 0), (2, 128, 20, 32, 64, 3, 0), (5, 128, 8, 32, 128, 3, 1), (3, 128, 16, 96, 64, 3, 0)]
 
 
 def main_ws64():

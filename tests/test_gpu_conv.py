@@ -44,10 +44,12 @@ CASES = [  # N, Ci, H, W, Co, K, stride, pad, up
     (1, 128, 48, 32, 128, 3, 1, 1, 0),
     # ... and more workgroups than CUs (36 x 4 x 2 = 288 tiles of 16 x 32 x 128: a second round of workgroups on some CUs)
     (36, 64, 32, 64, 256, 3, 1, 1, 0),
-    # weight-stationary kernel (conv3x3_ws64.hpp: Ci == 64) at its default threshold of 4 x 256 tiles: one and two channel tiles
+    # weight-stationary kernel (conv3x3_ws.hpp, Ci == 64 instantiation) at its default threshold of 4 x 256 tiles: one and two channel tiles
     # (the data gradient of the first case runs it too: Co = 64 there)
     (16, 64, 128, 128, 64, 3, 1, 1, 0),
     (8, 64, 128, 128, 128, 3, 1, 1, 0),
+    # ... and its Ci = 128 instantiation (4 x 32-pixel tiles; threshold 24 x 256 tiles = 12 per workgroup): four channel tiles
+    (12, 128, 128, 128, 256, 3, 1, 1, 0),
 ]
 
 
@@ -324,7 +326,7 @@ def test_ping_pong_halo_variant_passes_the_same_cases():
                         "fwd or dgrad or statistics or slices or upsampled"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:]
     code = DTYPE_CODE[torch.bfloat16]
-    assert lib.mi355_conv2d_igemm_variant(32, 64, 128, 32, 64, 64, 3, 3, 1, 1, -1, 1, 0, code) == 2          # default: the 4-wave kernel
+    assert lib.mi355_conv2d_igemm_variant(32, 64, 96, 32, 64, 64, 3, 3, 1, 1, -1, 1, 0, code) == 2           # default: the 4-wave kernel
 
 
 def test_128_channel_ping_pong_variant_passes_the_same_cases():
@@ -346,7 +348,7 @@ def test_128_channel_ping_pong_variant_passes_the_same_cases():
     assert r.returncode == 0, r.stdout[-3000:]
     code = DTYPE_CODE[torch.bfloat16]
     assert lib.mi355_conv2d_igemm_variant(32, 64, 256, 32, 64, 128, 3, 3, 1, 1, -1, 1, 0, code) == 6
-    assert lib.mi355_conv2d_igemm_variant(32, 64, 128, 32, 64, 128, 3, 3, 1, 1, -1, 1, 0, code) == 2
+    assert lib.mi355_conv2d_igemm_variant(32, 64, 128, 32, 64, 128, 3, 3, 1, 1, -1, 1, 0, code) == 8          # (Ci = 128: weight-stationary)
     assert lib.mi355_conv2d_igemm_variant(32, 64, 256, 32, 64, 64, 3, 3, 1, 1, -1, 1, 0, code) == 2
     # one 512-thread workgroup per CU: a batch whose grid does not fill the chip is served by the 4-wave kernel, and the statistics-
     # row query (which knows N) follows the launcher — 32 x 32 x 512 -> 512: 32 images = 256 workgroups of 16 x 32 x 128, 16 images = 128
@@ -355,7 +357,7 @@ def test_128_channel_ping_pong_variant_passes_the_same_cases():
 
 
 def test_weight_stationary_kernel_is_bit_identical_to_the_halo_kernel(tmp_path):
-    """conv3x3_ws64.hpp (Ci = 64: weights stationary in registers, persistent workgroups, the default from two tiles per
+    """conv3x3_ws.hpp (Ci = 64 / 128: weights stationary in registers, persistent workgroups, the default from two tiles per
     workgroup up) accumulates every output element in the SAME order as the 4-wave halo kernel — (slab, patch column, tap row)
     with the bias as the first C operand — so its outputs must be BIT-identical to that kernel's (MI355_WS64=0) on every case:
     forward, bias + ReLU into a channel slice, accumulating data gradients, fused up-sampling with the 2x2-sum epilogue, uneven
@@ -364,7 +366,7 @@ def test_weight_stationary_kernel_is_bit_identical_to_the_halo_kernel(tmp_path):
     import os, subprocess, sys
     here = os.path.dirname(os.path.abspath(__file__))
     outs = {}
-    for tag, env in (("ws64", {"MI355_WS64": "1", "MI355_WS64_MIN_TILES": "8"}), ("halo", {"MI355_WS64": "0"})):
+    for tag, env in (("ws64", {"MI355_WS64": "1", "MI355_WS128": "1", "MI355_WS64_MIN_TILES": "8"}), ("halo", {"MI355_WS64": "0", "MI355_WS128": "0"})):
         out = str(tmp_path / f"{tag}.npz")
         r = subprocess.run([sys.executable, os.path.join(here, "conv_dump_worker.py"), out], env=dict(os.environ, MI355_DUMP_SET="ws64", **env),
                            capture_output=True, text=True, timeout=300)
@@ -372,18 +374,19 @@ def test_weight_stationary_kernel_is_bit_identical_to_the_halo_kernel(tmp_path):
         outs[tag] = np.load(out)
     a, b = outs["ws64"], outs["halo"]
     assert set(a.files) == set(b.files)
-    n_ws = 0
+    n_ws = n_ws128 = 0
     for k in a.files:
         if "_variant_" in k:
             n_ws += int(a[k]) == 7
-            assert int(b[k]) != 7
+            n_ws128 += int(a[k]) == 8
+            assert int(b[k]) not in (7, 8)
         elif "_stats" in k:
             assert np.allclose(a[k], b[k], rtol=2e-5, atol=1e-2), k
         else:
             assert np.array_equal(a[k], b[k]), k
             if k.endswith("0"):
                 assert np.array_equal(a[k], a[k[:-1] + "1"]), k
-    assert n_ws >= 14          # every forward with Ci = 64 and every data gradient with Co = 64 ran the new kernel
+    assert n_ws >= 14 and n_ws128 >= 10      # forwards with Ci = 64 / 128 and data gradients with Co = 64 / 128 ran the new kernels
 
 
 def test_weight_stationary_variant_dispatch():
@@ -392,7 +395,13 @@ def test_weight_stationary_variant_dispatch():
     code = DTYPE_CODE[torch.bfloat16]
     assert lib.mi355_conv2d_igemm_variant(256, 256, 64, 256, 256, 64, 3, 3, 1, 1, -1, 1, 0, code) == 7
     assert lib.mi355_conv2d_igemm_variant(256, 256, 64, 256, 256, 128, 3, 3, 1, -1, 1, 1, 0, code) == 7           # data gradient 64 -> 128
-    assert lib.mi355_conv2d_igemm_variant(256, 256, 128, 256, 256, 64, 3, 3, 1, 1, -1, 1, 0, code) == 2
+    assert lib.mi355_conv2d_igemm_variant(256, 256, 128, 256, 256, 64, 3, 3, 1, 1, -1, 1, 0, code) == 8            # Ci = 128: the 4-row instantiation
+    assert lib.mi355_conv2d_igemm_variant(64, 64, 128, 64, 64, 256, 3, 3, 1, 1, -1, 1, 0, code) == 8
+    assert lib.mi355_conv2d_igemm_variant_n(32, 128, 128, 128, 128, 128, 128, 3, 3, 1, 1, -1, 1, 0, code) == 8
+    assert lib.mi355_conv2d_igemm_variant_n(2, 64, 64, 128, 64, 64, 128, 3, 3, 1, 1, -1, 1, 0, code) == 2          # 128 tiles: too few
+    assert lib.mi355_conv2d_igemm_variant_n(16, 128, 128, 128, 128, 128, 128, 3, 3, 1, 1, -1, 1, 0, code) == 2     # 8 tiles per workgroup: the 4-wave kernel
+    assert lib.mi355_conv2d_igemm_variant_n(32, 64, 64, 128, 64, 64, 256, 3, 3, 1, 1, -1, 1, 0, code) == 2
+    assert lib.mi355_conv2d_igemm_stat_rows(32, 128, 128, 128, 128, 128, 128, 3, 3, 1, 1, -1, 1, 0, code) == 32 * 32 * 4
     assert lib.mi355_conv2d_igemm_variant(16, 16, 64, 16, 16, 64, 3, 3, 1, 1, -1, 1, 0, code) == 3
     assert lib.mi355_conv2d_igemm_variant_n(32, 256, 256, 64, 256, 256, 64, 3, 3, 1, 1, -1, 1, 0, code) == 7
     assert lib.mi355_conv2d_igemm_variant_n(2, 64, 64, 64, 64, 64, 64, 3, 3, 1, 1, -1, 1, 0, code) == 2           # 32 tiles: too few

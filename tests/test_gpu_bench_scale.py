@@ -96,10 +96,10 @@ SCALE_CASES = {
     # 4-wave kernel (16 images of 32 x 32 do not fill the chip with 512-thread workgroups: resolve_variant's fall-back), one
     # multi-application weight-gradient launch per recurrent convolution.  Eval mode: a recurrent block adds its input six
     # times in front of an identity BatchNorm, activations reach 1e13 — fp32 and bf16 only.
-    "C4": (("conv3x3_ws_kernel<64,8>", "conv3x3_ws_kernel<128,4>", "conv3x3_halo_rw_kernel<8,32>", "conv3x3_halo_pp128_kernel", "wgrad3x3_halo_kernel"),
+    "C4": (("conv3x3_ws_kernel<64,8>", "conv3x3_halo_rw_kernel<8,32>", "conv3x3_halo_pp128_kernel", "wgrad3x3_halo_kernel"),
            {"MI355_WS64": "0"}, None),
     # AttentionUNet 512 x 512, batch 16 (C5's segmenter, fp16 in the configuration)
-    "C5seg": (("conv3x3_ws_kernel<64,8>", "conv3x3_halo_pp128_kernel", "wgrad3x3_halo_kernel"), {"MI355_HALO_PP128": "0"}, 4e-3),
+    "C5seg": (("conv3x3_ws_kernel<64,8>", "conv3x3_ws_kernel<128,4>", "conv3x3_halo_pp128_kernel", "wgrad3x3_halo_kernel"), {"MI355_HALO_PP128": "0"}, 4e-3),
     # vgg16_bn 512 x 512, batch 16 (C5's classifier): 13 conv + BN layers, the streaming 25088 -> 4096 -> 4096 head
     "C5cls": (("conv3x3_ws_kernel<64,8>", "conv3x3_halo_pp128_kernel", "wgrad3x3_halo_kernel"), {"MI355_WS64": "0"}, 4e-3),
     # ResNetUnet 256 x 256, batch 32, frozen ResNet-50 encoder (C2: fp32 in the configuration): strided / 1x1 / 7x7 / transposed

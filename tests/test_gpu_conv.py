@@ -366,7 +366,7 @@ def test_weight_stationary_kernel_is_bit_identical_to_the_halo_kernel(tmp_path):
     import os, subprocess, sys
     here = os.path.dirname(os.path.abspath(__file__))
     outs = {}
-    for tag, env in (("ws64", {"MI355_WS64": "1", "MI355_WS128": "1", "MI355_WS64_MIN_TILES": "8"}), ("halo", {"MI355_WS64": "0", "MI355_WS128": "0"})):
+    for tag, env in (("ws64", {"MI355_WS64": "1", "MI355_WS128": "1", "MI355_WS64_MIN_TILES": "1"}), ("halo", {"MI355_WS64": "0", "MI355_WS128": "0"})):
         out = str(tmp_path / f"{tag}.npz")
         r = subprocess.run([sys.executable, os.path.join(here, "conv_dump_worker.py"), out], env=dict(os.environ, MI355_DUMP_SET="ws64", **env),
                            capture_output=True, text=True, timeout=300)
@@ -383,7 +383,16 @@ def test_weight_stationary_kernel_is_bit_identical_to_the_halo_kernel(tmp_path):
         elif "_stats" in k:
             assert np.allclose(a[k], b[k], rtol=2e-5, atol=1e-2), k
         else:
-            assert np.array_equal(a[k], b[k]), k
+            # the comparison build runs the 4-wave halo kernel (variants 2 / 3: same accumulation order -> bit-identical) wherever
+            # the image divides into its tiles; an image with H % 8 == 4 goes to the LDS-DMA ring kernel there (another summation
+            # order): rounding-level agreement
+            which = k.split("_")[0] + "_" + k.split("_")[1] + ("_variant_dgrad" if "_dgrad" in k else "_variant_fwd")
+            if int(b[which]) in (2, 3):
+                assert np.array_equal(a[k], b[k]), k
+            else:
+                dt = torch.bfloat16 if "_bf16_" in k else torch.float16
+                fa, fb = (torch.from_numpy(v.copy()).view(dt).float() for v in (a[k], b[k]))
+                assert float((fa - fb).abs().max()) <= TOL[dt] * float(fb.abs().max()), k
             if k.endswith("0"):
                 assert np.array_equal(a[k], a[k[:-1] + "1"]), k
     assert n_ws >= 14 and n_ws128 >= 10      # forwards with Ci = 64 / 128 and data gradients with Co = 64 / 128 ran the new kernels

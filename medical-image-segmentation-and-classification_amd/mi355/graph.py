@@ -27,6 +27,7 @@ from .lib import lib, DTYPE_CODE
 BN_EPS_DEFAULT = 1e-5
 CPAD = 32          # network inputs are zero-padded to 32 channels (MFMA K granularity)
 FUSE_POOL = os.environ.get("MI355_FUSE_POOL", "1") != "0"      # MaxPool2d(2, 2) inside the BatchNorm apply pass that feeds it (A/B switch)
+FUSE_RESIDUAL = os.environ.get("MI355_FUSE_RESIDUAL", "1") != "0"   # RRCNN_block's x0 + RCNN(x0) inside the last BatchNorm apply pass (A/B switch)
 
 
 class T:
@@ -293,6 +294,7 @@ class Plan:
 
 class Builder:
     """Emits forward launches and registers reverse-mode rules; `finish()` returns a Plan."""
+    fuse_residual = FUSE_RESIDUAL
 
     def __init__(self, engine, device, dtype, training, want_grad):
         self.engine = engine

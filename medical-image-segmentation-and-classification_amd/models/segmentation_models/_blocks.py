@@ -47,18 +47,19 @@ class Recurrent_block(nn.Module):
         self.conv = nn.Sequential(nn.Conv2d(out_channels, out_channels, 3, 1, 1, bias=True),
                                   nn.BatchNorm2d(out_channels), nn.ReLU(inplace=True))
 
-    def lower(self, g, x):
+    def lower(self, g, x, plus=None, out=None):
         """x1 = f(x); t times x1 = f(x + x1).  The weight pack is shared; BN statistics, running-stat
-        updates and gradients are per application, in application order."""
+        updates and gradients are per application, in application order.  ``plus``: a tensor added to the block's OUTPUT in
+        the last application's BatchNorm apply pass (the residual sum of RRCNN_block, R2AttU_Net.py:59: no pass of its own)."""
         conv, bn = self.conv[0], self.conv[1]
         if self.t == 0:
-            return g.conv_bn_act(x, conv, bn, act=True)
+            return g.conv_bn_act(x, conv, bn, act=True, post_add=plus, out=out)
         # every application but the last emits s = x + relu(bn(conv(.))) directly (the next application's
         # input); x1 itself is never materialised except as the block output
         s = g.conv_bn_act(x, conv, bn, act=True, post_add=x)
         for _ in range(self.t - 1):
             s = g.conv_bn_act(s, conv, bn, act=True, post_add=x)
-        return g.conv_bn_act(s, conv, bn, act=True)
+        return g.conv_bn_act(s, conv, bn, act=True, post_add=plus, out=out)
 
 
 class RRCNN_block(nn.Module):
@@ -72,5 +73,7 @@ class RRCNN_block(nn.Module):
 
     def lower(self, g, x, out=None):
         x0 = g.conv_act(x, self.conv_1x1, relu=False)
-        x1 = self.RCNN[1].lower(g, self.RCNN[0].lower(g, x0))
-        return g.add(x0, x1, out=out)
+        # x0 + RCNN(x0): the sum rides in the last recurrent application's BatchNorm apply pass, its gradient in that pass's backward
+        if not g.fuse_residual:
+            return g.add(x0, self.RCNN[1].lower(g, self.RCNN[0].lower(g, x0)), out=out)
+        return self.RCNN[1].lower(g, self.RCNN[0].lower(g, x0), plus=x0, out=out)

@@ -188,6 +188,20 @@ int mi355_bn_bwd_apply(const void* dy, int lddy, const void* y, int ldy, const v
                        const float* mshift, const float* sums, void* dx, int lddx, void* dres, int lddres,
                        void* dpost, int lddpost, int post_acc, float* dbias_partial,
                        long long M, int C, int act, int dtype, mi355_stream_t s);
+/* The same two passes for a BatchNorm + ReLU layer whose activation also feeds a MaxPool2d(2, 2) (mi355_bn_act_pool2;
+ * AttentionUNet.py:61,89-95): dp, the gradient of the POOLED tensor [N][H/2][W/2][C], is added on the fly to the pixels that are
+ * the first maximum of their window (torch's tie rule, the activation recomputed from x with mscale / mshift exactly as the
+ * forward rounded it), so mi355_maxpool_bwd's pass over dy is not run: g = relu'(.) * (dy + [first max] * dp).  partial / sums /
+ * dx as in mi355_bn_bwd_reduce / _apply with act = 1 and no y.  mi355_bn_bwd_pool2_ok: 1 when the window-ordered pass covers the
+ * geometry (C / (16 / element size) a power of two <= 32, W a power-of-two multiple of 512 / that), else use the separate passes. */
+int mi355_bn_bwd_pool2_ok(int H, int W, int C, int dtype);
+int mi355_bn_bwd_reduce_pool2_rows(long long M);      /* partial rows mi355_bn_bwd_reduce_pool2 can leave non-zero (cf. mi355_bn_bwd_reduce_rows) */
+int mi355_bn_bwd_reduce_pool2(const void* dy, int lddy, const void* dp, int lddp, const void* x, int ldx, const float* mean,
+                              const float* invstd, const float* mscale, const float* mshift, float* partial,
+                              int N, int H, int W, int C, int dtype, mi355_stream_t s);
+int mi355_bn_bwd_apply_pool2(const void* dy, int lddy, const void* dp, int lddp, const void* x, int ldx, const float* gamma,
+                             const float* mean, const float* invstd, const float* mscale, const float* mshift,
+                             const float* sums, void* dx, int lddx, int N, int H, int W, int C, int dtype, mi355_stream_t s);
 /* out[c] (+)= sum_b partial[b*stride*C + c]  (used for conv bias gradients). */
 int mi355_colsum_finalize(const float* partial, int nblocks, int stride, int C, float* out, float acc,
                           mi355_stream_t s);

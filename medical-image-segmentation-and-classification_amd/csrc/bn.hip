@@ -224,7 +224,7 @@ template <typename T> struct BnActOp {
   __device__ void finish(const In& in, size_t row, int c0) const {
     float f[EPC];
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) f[e] = to_f32<T>(in.v.v[e]) * sc[e] + sh[e];
+    for (int e = 0; e < EPC; ++e) f[e] = __builtin_fmaf(to_f32<T>(in.v.v[e]), sc[e], sh[e]);      // (fused: the pool-aware backward recomputes it bit for bit)
     if (x2) {
 #pragma unroll
       for (int e = 0; e < EPC; ++e) f[e] += to_f32<T>(in.v2.v[e]) * sc2[e];
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void bn_act_pool2_kernel(const T* __restrict__
       Vec16<T> o;
 #pragma unroll
       for (int e = 0; e < EPC; ++e) {
-        float v = to_f32<T>(in[k].v[e]) * sc[e] + sh[e];
+        float v = __builtin_fmaf(to_f32<T>(in[k].v[e]), sc[e], sh[e]);
         if (act & 1) v = fmaxf(v, 0.f);
         o.v[e] = from_f32<T>(v);
         const float r = to_f32<T>(o.v[e]);
@@ -482,6 +482,168 @@ extern "C" int mi355_bn_bwd_apply(const void* dy, int lddy, const void* y, int l
 }
 
 // ---- plain column sums (bias gradients) -------------------------------------------------------------
+// ---- BatchNorm(+ReLU) backward of a layer whose activation also feeds a fused MaxPool2d(2, 2) (mi355_bn_act_pool2) -------------
+// The pooled tensor's gradient dp is NOT scattered into the activation's gradient by a pass of its own (mi355_maxpool_bwd: read
+// da, a and dp, write da): both BatchNorm passes add it on the fly, g = da + [pixel is the FIRST maximum of its window] * dp, with
+// the activation recomputed from the raw convolution output exactly as the forward rounded it.  A thread owns one 2 x 2 window per
+// batch (the mapping of bn_act_pool2_kernel: a wave instruction covers 64 / tpr pixels two apart, the four together every byte of
+// two image-row segments), a workgroup pass rp windows = two image rows x 2 * rp pixels.  Geometry the host checks: tpr = C / EPC
+// a power of two, W a power-of-two multiple of 2 * rp.
+template <typename T> struct BnBwdPool2 {
+  static constexpr int EPC = 16 / (int)sizeof(T);
+  const T* dy; int lddy; const T* dp; int lddp; const T* x; int ldx;
+  const float* mean; const float* invstd; const float* mscale; const float* mshift;
+  int W, lrp, lwb;               // rp = 1 << lrp windows of a workgroup pass, W = (2 * rp) << lwb
+  float mu[EPC], is[EPC], ms[EPC], mt[EPC];
+  __device__ void load_common(int c0) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { mu[e] = mean[c0 + e]; is[e] = invstd[c0 + e]; ms[e] = mscale[c0 + e]; mt[e] = mshift[c0 + e]; }
+  }
+  struct Px { size_t pix[4]; Vec16<T> gv[4], xv[4], pv; };      // rows in window scan order: (h, w), (h, w + 1), (h + 1, w), (h + 1, w + 1)
+  __device__ void fetch(long long r, int ty, int c0, Px& p) const {
+    const long long q = r >> (lrp + 2);                    // batch index
+    const long long R = q >> lwb;                          // pair of image rows (pairs never straddle images: H is even)
+    const int wcol = ((int)(q & ((1 << lwb) - 1)) << lrp) + ty;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) p.pix[b] = (size_t)(2 * R + (b >> 1)) * W + 2 * wcol + (b & 1);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      p.gv[b] = ld16_nt<T>(dy + p.pix[b] * lddy + c0);
+      p.xv[b] = ld16_nt<T>(x + p.pix[b] * ldx + c0);
+    }
+    p.pv = ld16_nt<T>(dp + ((size_t)R * (W >> 1) + wcol) * lddp + c0);
+  }
+  // g[b]: the gradient reaching the activation of row b, ReLU-masked
+  __device__ void grads(const Px& p, int e, float (&g)[4]) const {
+    float a[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) a[b] = to_f32<T>(from_f32<T>(fmaxf(__builtin_fmaf(to_f32<T>(p.xv[b].v[e]), ms[e], mt[e]), 0.f)));
+    // first maximum in scan order (torch's tie rule, mi355_maxpool_bwd): the earliest element equal to the window's maximum
+    const float mx = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
+    const bool w0 = a[0] == mx, w1 = !w0 && a[1] == mx, w2 = !(w0 || w1) && a[2] == mx, w3 = !(w0 || w1 || w2);
+    const float pg = to_f32<T>(p.pv.v[e]);
+    const bool win[4] = {w0, w1, w2, w3};
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const float t = to_f32<T>(p.gv[b].v[e]) + (win[b] ? pg : 0.f);
+      g[b] = a[b] > 0.f ? t : 0.f;
+    }
+  }
+};
+
+template <typename T> struct BnBwdReducePool2Op : BnBwdPool2<T> {
+  static constexpr int NQ = 2;
+  static constexpr bool WRITES = false;
+  static constexpr int BATCH_ROWS = 4;
+  typedef float Acc;
+  static constexpr int EPC = 16 / (int)sizeof(T);
+  __device__ void load_cols(int c0) { this->load_common(c0); }
+  __device__ void finish(const typename BnBwdPool2<T>::Px& p, int, int, Acc (&acc)[NQ][EPC]) const {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      float g[4];
+      this->grads(p, e, g);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        acc[0][e] += g[b];
+        acc[1][e] += g[b] * (to_f32<T>(p.xv[b].v[e]) - this->mu[e]) * this->is[e];
+      }
+    }
+  }
+};
+
+template <typename T> struct BnBwdApplyPool2Op : BnBwdPool2<T> {
+  static constexpr int NQ = 1;
+  static constexpr bool WRITES = true;
+  static constexpr int BATCH_ROWS = 4;
+  typedef float Acc;
+  static constexpr int EPC = 16 / (int)sizeof(T);
+  const float* gamma; const float* sums; T* dx; int lddx; float invM; int C;
+  float k0[EPC], k1[EPC], gi[EPC];
+  __device__ void load_cols(int c0) {
+    this->load_common(c0);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      gi[e] = gamma[c0 + e] * this->is[e];
+      k0[e] = sums[c0 + e] * invM;
+      k1[e] = sums[C + c0 + e] * invM;
+    }
+  }
+  __device__ void finish(const typename BnBwdPool2<T>::Px& p, int, int c0, Acc (&acc)[NQ][EPC]) const {
+    Vec16<T> o[4];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      float g[4];
+      this->grads(p, e, g);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const float xh = (to_f32<T>(p.xv[b].v[e]) - this->mu[e]) * this->is[e];
+        const float d = gi[e] * (g[b] - k0[e] - xh * k1[e]);
+        o[b].v[e] = from_f32<T>(d);
+        acc[0][e] += d;
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) st16<T>(dx + p.pix[b] * lddx + c0, o[b]);
+  }
+};
+
+// log2 of a power of two, -1 otherwise
+static inline int exact_log2(long long v) {
+  if (v <= 0 || (v & (v - 1))) return -1;
+  int l = 0;
+  while ((1LL << l) < v) ++l;
+  return l;
+}
+
+extern "C" int mi355_bn_bwd_reduce_pool2_rows(long long M) { return rowred_grid<BnBwdReducePool2Op<bf16_t>>(M); }
+
+extern "C" int mi355_bn_bwd_pool2_ok(int H, int W, int C, int dtype) {
+  const int epc = dtype_is_2byte(dtype) ? 8 : 4;
+  if (C % epc || H % 2 || W % 2) return 0;
+  const int tpr = C / epc;
+  if (tpr > 256 || exact_log2(tpr) < 0) return 0;
+  const int rp = 256 / tpr;
+  return W % (2 * rp) == 0 && exact_log2(W / (2 * rp)) >= 0;
+}
+
+template <typename T, typename Op> static void fill_pool2(Op& op, const void* dy, int lddy, const void* dp, int lddp, const void* x, int ldx,
+                                                          const float* mean, const float* invstd, const float* mscale,
+                                                          const float* mshift, int W, int C) {
+  const int tpr = C / (16 / (int)sizeof(T)), rp = 256 / tpr;
+  op.dy = (const T*)dy; op.lddy = lddy; op.dp = (const T*)dp; op.lddp = lddp; op.x = (const T*)x; op.ldx = ldx;
+  op.mean = mean; op.invstd = invstd; op.mscale = mscale; op.mshift = mshift;
+  op.W = W; op.lrp = exact_log2(rp); op.lwb = exact_log2(W / (2 * rp));
+}
+
+extern "C" int mi355_bn_bwd_reduce_pool2(const void* dy, int lddy, const void* dp, int lddp, const void* x, int ldx, const float* mean,
+                                         const float* invstd, const float* mscale, const float* mshift, float* partial,
+                                         int N, int H, int W, int C, int dtype, mi355_stream_t s) {
+  MI355_CHECK_ARG(dy && dp && x && mean && invstd && mscale && mshift && partial && N > 0, "bn_bwd_reduce_pool2: null pointer");
+  MI355_CHECK_ARG(mi355_bn_bwd_pool2_ok(H, W, C, dtype), "bn_bwd_reduce_pool2: %d x %d x %d is not a geometry of the window-ordered pass", H, W, C);
+  return dispatch_dtype(dtype, "bn_bwd_reduce_pool2", [&](auto tag) {
+    using T = decltype(tag);
+    BnBwdReducePool2Op<T> op;
+    fill_pool2<T>(op, dy, lddy, dp, lddp, x, ldx, mean, invstd, mscale, mshift, W, C);
+    return rowred_launch<T>(op, (long long)N * H * W, C, partial, (hipStream_t)s);
+  });
+}
+
+extern "C" int mi355_bn_bwd_apply_pool2(const void* dy, int lddy, const void* dp, int lddp, const void* x, int ldx, const float* gamma,
+                                        const float* mean, const float* invstd, const float* mscale, const float* mshift,
+                                        const float* sums, void* dx, int lddx, int N, int H, int W, int C, int dtype, mi355_stream_t s) {
+  MI355_CHECK_ARG(dy && dp && x && gamma && mean && invstd && mscale && mshift && sums && dx && N > 0, "bn_bwd_apply_pool2: null pointer");
+  MI355_CHECK_ARG(mi355_bn_bwd_pool2_ok(H, W, C, dtype), "bn_bwd_apply_pool2: %d x %d x %d is not a geometry of the window-ordered pass", H, W, C);
+  const long long M = (long long)N * H * W;
+  return dispatch_dtype(dtype, "bn_bwd_apply_pool2", [&](auto tag) {
+    using T = decltype(tag);
+    BnBwdApplyPool2Op<T> op;
+    fill_pool2<T>(op, dy, lddy, dp, lddp, x, ldx, mean, invstd, mscale, mshift, W, C);
+    op.gamma = gamma; op.sums = sums; op.dx = (T*)dx; op.lddx = lddx; op.invM = (float)(1.0 / (double)M); op.C = C;
+    return rowred_launch<T>(op, M, C, nullptr, (hipStream_t)s);
+  });
+}
+
 template <typename T> struct ColSumOp {
   static constexpr int NQ = 1;
   static constexpr bool WRITES = false;

@@ -48,6 +48,11 @@ template <typename Op, typename = void> struct has_max_wgs : std::false_type {};
 template <typename Op> struct has_max_wgs<Op, std::void_t<decltype(Op::MAX_WGS)>> : std::true_type {};
 template <typename Op, typename = void> struct has_fetch : std::false_type {};
 template <typename Op> struct has_fetch<Op, std::void_t<typename Op::In>> : std::true_type {};
+// An op with `static constexpr int BATCH_ROWS`, `struct Px`, `fetch(r, ty, c0, Px&)` and `finish(Px&, ty, c0, acc)` maps each batch of BATCH_ROWS * rp consecutive "virtual"
+// rows (r = its first one) to pixels ITSELF (2 x 2-window aware orders); M is a multiple of the batch and every thread is
+// active (the host checks both).
+template <typename Op, typename = void> struct has_batch : std::false_type {};
+template <typename Op> struct has_batch<Op, std::void_t<decltype(Op::BATCH_ROWS)>> : std::true_type {};
 
 // Op contract:
 //   static constexpr int NQ;                       number of reduced quantities
@@ -76,7 +81,17 @@ __global__ __launch_bounds__(256) void rowred_kernel(Op op, RowRedGeom g, float*
     const long long r0 = (long long)blockIdx.x * g.rows_per_block;
     long long r1 = r0 + g.rows_per_block;
     if (r1 > g.M) r1 = g.M;
-    if constexpr (has_fetch<Op>::value) {
+    if constexpr (has_batch<Op>::value) {
+      // (issuing the next batch's loads before the current one's arithmetic — ping-pong register sets — and two or three workgroups
+      // per CU were measured within noise of this loop: profiles/r03c_ab_poolbwd.txt)
+      constexpr int B = Op::BATCH_ROWS;
+      const long long st = (long long)gridDim.x * g.rp * B;
+      for (long long r = (long long)blockIdx.x * g.rp * B; r < g.M; r += st) {
+        typename Op::Px p;
+        op.fetch(r, ty, c0, p);
+        op.finish(p, ty, c0, acc);
+      }
+    } else if constexpr (has_fetch<Op>::value) {
       // ops that also store: the compiler may not move a load above the previous row's store (the tensors can alias), so
       // the rows of a trip are fetched explicitly before any of them is finished — FETCH_ROWS x the bytes in flight
       // A workgroup pass covers B * rp consecutive rows and the grid sweeps the tensor as one moving window (workgroups that
@@ -143,7 +158,7 @@ __global__ __launch_bounds__(256) void rowred_kernel(Op op, RowRedGeom g, float*
 template <typename Op> static inline int rowred_grid(long long M) {
   int nb = rowreduce_blocks(M);
   static const int rr_wgs = getenv("MI355_RR_WGS") ? atoi(getenv("MI355_RR_WGS")) : 0;      // (A/B switch: one cap for every op)
-  if constexpr (has_fetch<Op>::value) {
+  if constexpr (has_fetch<Op>::value || has_batch<Op>::value) {
     int cap = 256;
     if constexpr (has_max_wgs<Op>::value) cap = Op::MAX_WGS;      // (narrow rows: rowdot_bwd 256 / 512 / 1024 workgroups = 0.307 / 0.218 / 0.212 ms per step)
     if (rr_wgs > 0) cap = rr_wgs;

@@ -27,12 +27,13 @@ from .lib import lib, DTYPE_CODE
 BN_EPS_DEFAULT = 1e-5
 CPAD = 32          # network inputs are zero-padded to 32 channels (MFMA K granularity)
 FUSE_POOL = os.environ.get("MI355_FUSE_POOL", "1") != "0"      # MaxPool2d(2, 2) inside the BatchNorm apply pass that feeds it (A/B switch)
+FUSE_POOL_BWD = os.environ.get("MI355_FUSE_POOL_BWD", "1") != "0"   # ... and its gradient inside that layer's two BatchNorm backward passes
 FUSE_RESIDUAL = os.environ.get("MI355_FUSE_RESIDUAL", "1") != "0"   # RRCNN_block's x0 + RCNN(x0) inside the last BatchNorm apply pass (A/B switch)
 
 
 class T:
     """NHWC activation handle: rows of C channels with channel stride ld inside `buf`."""
-    __slots__ = ("buf", "off", "N", "H", "W", "C", "ld", "_ng", "_grad", "parent", "_written", "name")
+    __slots__ = ("buf", "off", "N", "H", "W", "C", "ld", "_ng", "_grad", "parent", "_written", "name", "_plain_bn_relu", "_lazy_pool")
 
     def __init__(self, buf, off, N, H, W, C, ld, parent=None):
         self.buf, self.off = buf, off
@@ -42,6 +43,8 @@ class T:
         self.parent = parent
         self._written = False
         self.name = ""
+        self._plain_bn_relu = False     # relu(bn(conv(.))) with nothing added: produced by Builder.conv_bn_act in training
+        self._lazy_pool = None          # gradient of a MaxPool2d(2, 2) of this tensor left to the producer's BatchNorm backward
 
     @property
     def needs_grad(self):
@@ -628,11 +631,31 @@ class Builder:
                                    C, st["scale"], st["shift"]))
         return st
 
-    def _bn_bwd(self, da, a, y, bn, st, act, dres_to=None, bias=None, post_to=None):
-        """Emit BN(+ReLU) backward: returns dy (grad of the raw input y)."""
+    def _bn_bwd(self, da, a, y, bn, st, act, dres_to=None, bias=None, post_to=None, pool_dp=None):
+        """Emit BN(+ReLU) backward: returns dy (grad of the raw input y).  ``pool_dp``: the gradient of a MaxPool2d(2, 2) of the
+        activation that maxpool() left for these passes to add on the fly (no mi355_maxpool_bwd pass over da)."""
         C = bn.num_features
         nb = lib.mi355_rowreduce_blocks(y.M)
         part = self.ws_f32(nb * 2 * C)
+        if pool_dp is not None:
+            assert act and dres_to is None and post_to is None
+            self.bwd.append(Launch("mi355_bn_bwd_reduce_pool2", da, da.ld, pool_dp, pool_dp.ld, y, y.ld, st["mean"], st["invstd"],
+                                   st["scale"], st["shift"], part, y.N, y.H, y.W, C, self.code, nbytes=int(2.25 * y.M * C * self.esz)))
+            sums = self.f32(2 * C)
+            need_pg = bn.weight.requires_grad
+            if need_pg:
+                gref, gbeta = self.pgrad(bn.weight)
+                bref, _ = self.pgrad(bn.bias)
+            self.bwd.append(Launch("mi355_bn_bwd_finalize", part, min(nb, lib.mi355_bn_bwd_reduce_pool2_rows(y.M)), C, sums,
+                                   gref if need_pg else None, bref if need_pg else None, gbeta if need_pg else 0.0))
+            dy = self.grad_of(y)
+            if bias is not None and bias.requires_grad and id(bias) not in self._grad_first:
+                self.pgrad(bias)
+                self.zero_grad_params.append(bias)
+            self.bwd.append(Launch("mi355_bn_bwd_apply_pool2", da, da.ld, pool_dp, pool_dp.ld, y, y.ld, bn.weight, st["mean"],
+                                   st["invstd"], st["scale"], st["shift"], sums, dy, dy.ld, y.N, y.H, y.W, C, self.code,
+                                   nbytes=int(3.25 * y.M * C * self.esz)))
+            return dy
         # the ReLU mask is recomputed from the raw input with the forward's coefficients unless something was
         # added in front of the ReLU (residual / second operand), in which case the activated tensor is read
         am = a if (act and dres_to is not None) else None
@@ -714,13 +737,14 @@ class Builder:
         a.needs_grad = y.needs_grad or bn.weight.requires_grad or (r is not None and r.needs_grad)
         if act:
             self.acts.append(("relu", a) if post_add is None else ("relu_pre", y, st["scale"], st["shift"]))
+        a._plain_bn_relu = bool(act and r is None and self.training)      # (maxpool(): its gradient may ride in this layer's backward)
 
         def rule():
             if not a.needs_grad:
                 return
             da = self.grad_of(a)
             # d(x + relu(.)) / dx = identity: folded into the BatchNorm apply pass
-            dy = self._bn_bwd(da, a, y, bn, st, act, dres_to=res, bias=conv.bias, post_to=post_add)
+            dy = self._bn_bwd(da, a, y, bn, st, act, dres_to=res, bias=conv.bias, post_to=post_add, pool_dp=getattr(a, "_lazy_pool", None))
             conv_bwd(dy, bias_done=True)
         self.rule(rule)
         return a
@@ -822,6 +846,12 @@ class Builder:
                 return
             dy = self.grad_of(y)
             acc = self.acc_flag(x)
+            if (FUSE_POOL_BWD and acc and (k, s, p) == (2, 2, 0) and getattr(x, "_plain_bn_relu", False)
+                    and lib.mi355_bn_bwd_pool2_ok(x.H, x.W, x.C, self.code)):
+                # x = relu(bn(conv(.))) whose gradient already holds the other consumers' parts (they come later in the forward): the
+                # layer's two BatchNorm backward passes add the pooled gradient on the fly instead of a scatter pass over dx
+                x._lazy_pool = dy
+                return
             xg = self.grad_of(x)
             self.bwd.append(Launch("mi355_maxpool_bwd", x, x.ld, dy, dy.ld, xg, xg.ld, x.N, x.H, x.W, x.C, k, s, p, acc, self.code))
         self.rule(rule)

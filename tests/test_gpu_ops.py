@@ -177,6 +177,83 @@ def test_bn_act_with_fused_maxpool_is_bit_identical_to_the_two_passes(dtype, act
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(3, 64, 8, 64), (2, 128, 6, 32), (2, 256, 4, 32), (1, 32, 4, 256)])
+def test_bn_backward_with_lazy_maxpool_gradient(shape, dtype):
+    """mi355_bn_bwd_reduce_pool2 / _apply_pool2 (the gradient of the MaxPool2d(2, 2) of AttentionUNet.py:61,89-95 added inside the
+    two BatchNorm backward passes of the layer that produced the pooled activation) against the separate passes — mi355_bn_act,
+    mi355_maxpool_bwd accumulating into da, mi355_bn_bwd_reduce / _apply — through the same finalize, with operands in channel
+    slices of wider buffers.  The raw tensor is quantised so that windows TIE (also at zero, behind the ReLU): torch's first-maximum
+    rule.  fp32: the sums of the two orders agree to rounding; 2-byte: the separate passes round da + scatter to the storage type
+    first, the fused ones do not."""
+    n, c, h, w = shape
+    epc = 4 if dtype == torch.float32 else 8
+    if not lib.mi355_bn_bwd_pool2_ok(h, w, c, DTYPE_CODE[dtype]):
+        pytest.skip("row too short for this channel count")
+    g = torch.Generator().manual_seed(c + w)
+    code = DTYPE_CODE[dtype]
+    m = n * h * w
+    x = q(torch.round(torch.randn(n, c, h, w, generator=g) * 2) / 2, dtype)             # raw convolution output, many equal values
+    da = q(torch.randn(n, c, h, w, generator=g), dtype)
+    dp = q(torch.randn(n, c, h // 2, w // 2, generator=g), dtype)
+    gamma = torch.rand(c, generator=g) + 0.5
+    mean = x.float().mean((0, 2, 3)); var = x.float().var((0, 2, 3), unbiased=False)
+    invstd = (var + 1e-5).rsqrt()
+    beta = torch.randn(c, generator=g) * 0.3
+    sc, sh = gamma * invstd, beta - mean * gamma * invstd
+    # wider buffers: x at channel offset 8 of c + 8, da at 16 of c + 16, dp at 0 of c + 8, dx at 8 of c + 24
+    def wide(t, off, tot):
+        b = torch.zeros(t.shape[0], t.shape[2], t.shape[3], tot, dtype=dtype, device=DEV)
+        b[..., off:off + c] = to_nhwc(t, dtype)
+        return b
+    xb, dab0, dpb = wide(x, 8, c + 8), wide(da, 16, c + 16), wide(dp, 0, c + 8)
+    es = xb.element_size()
+    xp, dpp = xb.data_ptr() + 8 * es, dpb.data_ptr()
+    D = [dev(t.float().contiguous()) for t in (gamma, mean, invstd, sc, sh)]
+    res = []
+    for fused in (0, 1):
+        dab = dab0.clone()
+        dap = dab.data_ptr() + 16 * es
+        dxb = torch.zeros(n, h, w, c + 24, dtype=dtype, device=DEV)
+        dxp = dxb.data_ptr() + 8 * es
+        nb, part = _partials(m, c)
+        sums = torch.empty(2 * c, device=DEV); dg = torch.empty(c, device=DEV); db = torch.empty(c, device=DEV)
+        if fused:
+            lib.mi355_bn_bwd_reduce_pool2(dap, c + 16, dpp, c + 8, xp, c + 8, D[1], D[2], D[3], D[4], part, n, h, w, c, code)
+            lib.mi355_bn_bwd_finalize(part, min(nb, lib.mi355_bn_bwd_reduce_pool2_rows(m)), c, sums, dg, db, 0.0)
+            lib.mi355_bn_bwd_apply_pool2(dap, c + 16, dpp, c + 8, xp, c + 8, D[0], D[1], D[2], D[3], D[4], sums, dxp, c + 24, n, h, w, c, code)
+        else:
+            a = torch.empty(n, h, w, c, dtype=dtype, device=DEV)
+            lib.mi355_bn_act(xp, c + 8, D[3], D[4], None, 0, None, None, None, 0, a, c, m, c, 1, code)
+            lib.mi355_maxpool_bwd(a, c, dpp, c + 8, dap, c + 16, n, h, w, c, 2, 2, 0, 1, code)
+            lib.mi355_bn_bwd_reduce(dap, c + 16, None, 0, xp, c + 8, D[1], D[2], D[3], D[4], part, m, c, 1, code)
+            lib.mi355_bn_bwd_finalize(part, min(nb, lib.mi355_bn_bwd_reduce_rows(m)), c, sums, dg, db, 0.0)
+            lib.mi355_bn_bwd_apply(dap, c + 16, None, 0, xp, c + 8, D[0], D[1], D[2], D[3], D[4], sums, dxp, c + 24, None, 0, None, 0, 0,
+                                   None, m, c, 1, code)
+        torch.cuda.synchronize()
+        if fused:
+            assert torch.equal(dab, dab0)                       # the incoming gradient is only read
+        assert float(dxb[..., :8].abs().sum()) == 0 and float(dxb[..., 8 + c:].abs().sum()) == 0
+        res.append((dxb[..., 8:8 + c].float().cpu(), sums.cpu(), dg.cpu(), db.cpu()))
+    # torch: the composite on the CPU in fp32 (activation rounded to the storage type as the forward stores it)
+    xr = x.float().clone().requires_grad_(True)
+    act = F.relu(xr * sc[None, :, None, None] + sh[None, :, None, None])
+    # (BatchNorm with batch statistics: differentiate through mean / var of x)
+    xhat = (xr - xr.mean((0, 2, 3), keepdim=True)) * (xr.var((0, 2, 3), unbiased=False, keepdim=True) + 1e-5).rsqrt()
+    act2 = F.relu(xhat * gamma[None, :, None, None] + beta[None, :, None, None])
+    a_q = q(act.detach(), dtype)
+    aq = a_q.clone().requires_grad_(True)
+    F.max_pool2d(aq, 2, 2).backward(dp.float())
+    gtot = (da.float() + aq.grad)                                 # gradient reaching the activation
+    act2.backward(gtot)
+    tol = TOL[dtype]
+    for r in res:
+        assert rel_err(from_nhwc(r[0]), xr.grad) < (tol if dtype == torch.float32 else 2 * tol)
+    assert rel_err(res[1][1], res[0][1]) < (1e-5 if dtype == torch.float32 else tol)
+    assert rel_err(res[1][0], res[0][0]) < (1e-5 if dtype == torch.float32 else 2 * tol)
+    assert rel_err(res[1][2], res[0][2]) < (1e-5 if dtype == torch.float32 else tol)
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_upsample_bwd_add_relu(dtype):
     n, c, h, w = 2, 32, 5, 7
     g = torch.Generator().manual_seed(9)

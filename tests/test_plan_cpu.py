@@ -116,7 +116,19 @@ def test_maxpool_rides_in_the_batchnorm_apply_pass():
     plan = net.engine.plan_for((2, 3, 64, 64), True, True, torch.bfloat16)
     names = [l.name for l in plan.fwd]
     assert names.count("mi355_bn_act_pool2") == 4 and "mi355_maxpool_fwd" not in names
-    assert sum(l.name == "mi355_maxpool_bwd" for l in plan.bwd) == 4 and sum(a[0] == "pool" for a in plan.acts) == 4
+    assert sum(a[0] == "pool" for a in plan.acts) == 4
+    # ... and the pooling's gradient rides in the two BatchNorm backward passes of the layer that produced the pooled activation
+    # (no mi355_maxpool_bwd pass over its gradient)
+    bnames = [l.name for l in plan.bwd]
+    assert bnames.count("mi355_maxpool_bwd") == 0 and bnames.count("mi355_bn_bwd_reduce_pool2") == 4 \
+        and bnames.count("mi355_bn_bwd_apply_pool2") == 4
+    # a width the window-ordered pass does not cover (W = 40: not a power-of-two multiple of 64 pixels) keeps the separate pass
+    plan = net.engine.plan_for((1, 3, 80, 80), True, True, torch.bfloat16)
+    bnames = [l.name for l in plan.bwd]
+    assert bnames.count("mi355_maxpool_bwd") + bnames.count("mi355_bn_bwd_reduce_pool2") == 4 and "mi355_maxpool_bwd" in bnames
+    for i, nm in enumerate(bnames):
+        if nm == "mi355_bn_bwd_reduce_pool2":
+            assert bnames[i + 1] == "mi355_bn_bwd_finalize" and bnames[i + 2] == "mi355_bn_bwd_apply_pool2"
     plan.bind(0)                                   # ABI arity of the new entry point
 
 

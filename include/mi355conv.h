@@ -179,6 +179,9 @@ int mi355_bn_bwd_reduce(const void* dy, int lddy, const void* y, int ldy, const 
 /* sums[0..C) = sum g (dbeta), sums[C..2C) = sum g*xhat (dgamma); beta-accumulate into dgamma/dbeta. */
 int mi355_bn_bwd_finalize(const float* partial, int nblocks, int C, float* sums, float* dgamma, float* dbeta,
                           float acc, mi355_stream_t s);
+/* The same fold over partial rows of nq quantities per channel: (sum g, sum g*xhat) = quantities (q0, q1) of each row. */
+int mi355_bn_bwd_finalize_at(const float* partial, int nblocks, int nq, int q0, int q1, int C, float* sums, float* dgamma,
+                             float* dbeta, float acc, mi355_stream_t s);
 /* dx = gamma*invstd*(g - sum_g/M - xhat*sum_gx/M); optional dres = g (residual / second operand
  * gradient, pre-normalisation: the ReLU mask applied); optional dpost (+)= dy, the UNMASKED incoming gradient, for an
  * operand that was added AFTER the activation (x + relu(bn(.)), R2AttU_Net.py:44; post_acc != 0 accumulates) — the
@@ -250,6 +253,24 @@ int mi355_gate_mul_bwd(const void* dy, int lddy, const void* x, int ldx, const f
 /* scalar-field BN backward: dz = gamma*invstd*(dzn - S0/M - zhat*S1/M). */
 int mi355_bn1_bwd_apply(const float* dzn, const float* z, const float* gamma, const float* mean,
                         const float* invstd, const float* sums, float* dz, long long M, mi355_stream_t s);
+/* Backward of the gate's two normalised branches in two passes instead of mi355_rowdot_bwd + 2 x (mi355_bn_bwd_reduce,
+ * mi355_bn_bwd_apply) (AttentionUNet.py:32-38,48-52: psi_in = relu(BN_g(W_g g) + BN_x(W_x x)), z = psi conv).  g1 / x1 are the RAW
+ * branch convolution outputs, scale / shift / mean / invstd the forward's coefficients of the two BatchNorms, w the psi
+ * convolution's weight [C], dz the gradient of its output: the gradient of psi_in, dz[m] * w[c] where psi_in > 0, is recomputed
+ * on the fly (psi_in exactly as mi355_bn_act rounded it) and never stored.  reduce leaves FIVE quantities per channel and partial
+ * row — sum dp, sum dp * xhat_g, sum dp * xhat_x, sum dz * psi_in (the psi weight's gradient), sum dz (its bias's) — which
+ * mi355_bn_bwd_finalize_at (quantities (0, 1) and (0, 2) of 5) and mi355_colsum_finalize (stride 5) fold; apply writes the input
+ * gradients of both BatchNorms.  mi355_gate_bn_bwd_reduce_rows: the partial rows that can be non-zero. */
+int mi355_gate_bn_bwd_reduce_rows(long long M);
+int mi355_gate_bn_bwd_reduce(const float* dz, const void* g1, int ldg, const void* x1, int ldx, const float* scale_g,
+                             const float* shift_g, const float* mean_g, const float* invstd_g, const float* scale_x,
+                             const float* shift_x, const float* mean_x, const float* invstd_x, const float* w,
+                             float* partial, long long M, int C, int dtype, mi355_stream_t s);
+int mi355_gate_bn_bwd_apply(const float* dz, const void* g1, int ldg, const void* x1, int ldx, const float* scale_g,
+                            const float* shift_g, const float* mean_g, const float* invstd_g, const float* scale_x,
+                            const float* shift_x, const float* mean_x, const float* invstd_x, const float* w,
+                            const float* gamma_g, const float* gamma_x, const float* sums_g, const float* sums_x,
+                            void* dg1, int lddg, void* dx1, int lddx, long long M, int C, int dtype, mi355_stream_t s);
 
 /* ---- heads (ResNet.py:112-115, VGG.py:109-119) --------------------------------------------- */
 int mi355_global_pool_fwd(const void* x, int ldx, float* y, int32_t* argmax, int N, int HW, int C, int is_max,

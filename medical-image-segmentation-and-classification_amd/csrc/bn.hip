@@ -227,7 +227,7 @@ template <typename T> struct BnActOp {
     for (int e = 0; e < EPC; ++e) f[e] = __builtin_fmaf(to_f32<T>(in.v.v[e]), sc[e], sh[e]);      // (fused: the pool-aware backward recomputes it bit for bit)
     if (x2) {
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) f[e] += to_f32<T>(in.v2.v[e]) * sc2[e];
+      for (int e = 0; e < EPC; ++e) f[e] = __builtin_fmaf(to_f32<T>(in.v2.v[e]), sc2[e], f[e]);      // (mi355_gate_bn_bwd_* recompute it)
     }
     // act bit0: ReLU; bit1: the residual is added AFTER the activation (recurrent block x + relu(bn(.)),
     // R2AttU_Net.py:44) instead of before it (ResNet.py:43)
@@ -379,10 +379,10 @@ extern "C" int mi355_bn_bwd_reduce(const void* dy, int lddy, const void* y, int 
 template <int CH, int BL>
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int C,
                                                                float* __restrict__ sums, float* __restrict__ dgamma,
-                                                               float* __restrict__ dbeta, float accf) {
+                                                               float* __restrict__ dbeta, float accf, int nq, int q0, int q1) {
   __shared__ double red[2 * 16 * CH];
   double sums2[2];
-  fold_partials<CH, BL, 2>(partial, nblocks, 2 * C, {0, C}, C, red, sums2);
+  fold_partials<CH, BL, 2>(partial, nblocks, nq * C, {q0 * C, q1 * C}, C, red, sums2);
   const double s0 = sums2[0], s1 = sums2[1];
   const int c = blockIdx.x * CH + threadIdx.x;
   if (threadIdx.x >= CH || c >= C) return;
@@ -392,17 +392,23 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
   if (dgamma) dgamma[c] = (accf != 0.f ? accf * dgamma[c] : 0.f) + (float)s1;
 }
 
-extern "C" int mi355_bn_bwd_finalize(const float* partial, int nblocks, int C, float* sums, float* dgamma, float* dbeta,
-                                     float acc, mi355_stream_t s) {
+extern "C" int mi355_bn_bwd_finalize_at(const float* partial, int nblocks, int nq, int q0, int q1, int C, float* sums, float* dgamma,
+                                        float* dbeta, float acc, mi355_stream_t s) {
   MI355_CHECK_ARG(partial && sums, "bn_bwd_finalize: null pointer");
+  MI355_CHECK_ARG(nq >= 2 && q0 >= 0 && q0 < nq && q1 >= 0 && q1 < nq, "bn_bwd_finalize: quantities %d, %d of %d per partial row", q0, q1, nq);
   if (nblocks > 128)      // (see mi355_bn_finalize)
     hipLaunchKernelGGL((bn_bwd_finalize_kernel<4, 256>), dim3(ceil_div(C, 4)), dim3(1024), 0, (hipStream_t)s, partial, nblocks, C,
-                       sums, dgamma, dbeta, acc);
+                       sums, dgamma, dbeta, acc, nq, q0, q1);
   else
     hipLaunchKernelGGL((bn_bwd_finalize_kernel<32, 32>), dim3(ceil_div(C, 32)), dim3(1024), 0, (hipStream_t)s, partial, nblocks, C,
-                       sums, dgamma, dbeta, acc);
+                       sums, dgamma, dbeta, acc, nq, q0, q1);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
+}
+
+extern "C" int mi355_bn_bwd_finalize(const float* partial, int nblocks, int C, float* sums, float* dgamma, float* dbeta,
+                                     float acc, mi355_stream_t s) {
+  return mi355_bn_bwd_finalize_at(partial, nblocks, 2, 0, 1, C, sums, dgamma, dbeta, acc, s);
 }
 
 template <typename T> struct BnBwdApplyOp {

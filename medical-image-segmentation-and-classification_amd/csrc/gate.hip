@@ -151,6 +151,138 @@ extern "C" int mi355_rowdot_bwd(const float* dz, const void* x, int ldx, const f
   });
 }
 
+// ---- backward of the gate's two normalised branches, W_g / W_x (AttentionUNet.py:32-38,48-52) ---------------------------------
+// p = relu(bn_g(g1) + bn_x(x1)) feeds the one-channel psi convolution; given dz (the gradient of that convolution's output) the
+// gradient of p is dz[m] * w[c] where p > 0 — a tensor mi355_rowdot_bwd would write and FOUR BatchNorm passes (two branches x
+// reduce / apply) would read.  These two passes recompute p from the raw branch outputs exactly as mi355_bn_act rounded it and
+// serve both branches at once: reduce reads g1, x1 and dz and leaves five quantities per channel,
+//   q0 = sum dp, q1 = sum dp * xhat_g, q2 = sum dp * xhat_x, q3 = sum dz * p (the psi weight's gradient), q4 = sum dz (its bias's);
+// apply reads the same and writes both branches' input gradients.
+template <typename T> struct GateBnBwd {
+  static constexpr int EPC = 16 / (int)sizeof(T);
+  const float* dz; const T* g1; int ldg; const T* x1; int ldx;
+  const float* scale_g; const float* shift_g; const float* scale_x; const float* shift_x;
+  const float* mean_g; const float* invstd_g; const float* mean_x; const float* invstd_x; const float* w;
+  float sg[EPC], sx[EPC], sh[EPC], mg[EPC], ig[EPC], mx[EPC], ix[EPC], wr[EPC];
+  __device__ void load_common(int c0) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      sg[e] = scale_g[c0 + e]; sx[e] = scale_x[c0 + e]; sh[e] = shift_g[c0 + e] + shift_x[c0 + e];      // (BnActOp::load_cols)
+      mg[e] = mean_g[c0 + e]; ig[e] = invstd_g[c0 + e]; mx[e] = mean_x[c0 + e]; ix[e] = invstd_x[c0 + e];
+      wr[e] = w[c0 + e];
+    }
+  }
+  static constexpr int FETCH_ROWS = 4;
+  struct In { Vec16<T> gv, xv; float d; };
+  __device__ In fetch(size_t row, int c0) const {
+    return In{ld16_nt<T>(g1 + row * ldg + c0), ld16_nt<T>(x1 + row * ldx + c0), dz[row]};
+  }
+  // the activation as the forward stored it (BnActOp::finish with a second operand and ReLU)
+  __device__ float act(const In& in, int e) const {
+    const float f = __builtin_fmaf(to_f32<T>(in.xv.v[e]), sx[e], __builtin_fmaf(to_f32<T>(in.gv.v[e]), sg[e], sh[e]));
+    return to_f32<T>(from_f32<T>(fmaxf(f, 0.f)));
+  }
+  // ... and its gradient as mi355_rowdot_bwd would have STORED it (rounded to the storage type): the two-pass backward is then
+  // bit-identical to the separate passes, and a 2-byte training trajectory does not depend on which of the two ran
+  __device__ float dpsi(const In& in, int e, float p) const { return p > 0.f ? to_f32<T>(from_f32<T>(in.d * wr[e])) : 0.f; }
+};
+
+template <typename T> struct GateBnBwdReduceOp : GateBnBwd<T> {
+  static constexpr int NQ = 5;
+  static constexpr bool WRITES = false;
+  typedef float Acc;
+  static constexpr int EPC = 16 / (int)sizeof(T);
+  using typename GateBnBwd<T>::In;
+  __device__ void load_cols(int c0) { this->load_common(c0); }
+  __device__ void finish(const In& in, size_t, int, Acc (&acc)[NQ][EPC]) const {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const float p = this->act(in, e);
+      const float dp = this->dpsi(in, e, p);
+      acc[0][e] += dp;
+      acc[1][e] += dp * (to_f32<T>(in.gv.v[e]) - this->mg[e]) * this->ig[e];
+      acc[2][e] += dp * (to_f32<T>(in.xv.v[e]) - this->mx[e]) * this->ix[e];
+      acc[3][e] += in.d * p;
+      acc[4][e] += in.d;
+    }
+  }
+};
+
+template <typename T> struct GateBnBwdApplyOp : GateBnBwd<T> {
+  static constexpr int NQ = 1;
+  static constexpr bool WRITES = true;
+  typedef float Acc;
+  static constexpr int EPC = 16 / (int)sizeof(T);
+  using typename GateBnBwd<T>::In;
+  const float* gamma_g; const float* gamma_x; const float* sums_g; const float* sums_x;
+  T* dg; int lddg; T* dx; int lddx; float invM; int C;
+  float kg0[EPC], kg1[EPC], gg[EPC], kx0[EPC], kx1[EPC], gx[EPC];
+  __device__ void load_cols(int c0) {
+    this->load_common(c0);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      gg[e] = gamma_g[c0 + e] * this->ig[e]; kg0[e] = sums_g[c0 + e] * invM; kg1[e] = sums_g[C + c0 + e] * invM;
+      gx[e] = gamma_x[c0 + e] * this->ix[e]; kx0[e] = sums_x[c0 + e] * invM; kx1[e] = sums_x[C + c0 + e] * invM;
+    }
+  }
+  __device__ void finish(const In& in, size_t row, int c0, Acc (&)[NQ][EPC]) const {
+    Vec16<T> og, ox;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const float dp = this->dpsi(in, e, this->act(in, e));
+      const float hg = (to_f32<T>(in.gv.v[e]) - this->mg[e]) * this->ig[e];
+      const float hx = (to_f32<T>(in.xv.v[e]) - this->mx[e]) * this->ix[e];
+      og.v[e] = from_f32<T>(gg[e] * (dp - kg0[e] - hg * kg1[e]));
+      ox.v[e] = from_f32<T>(gx[e] * (dp - kx0[e] - hx * kx1[e]));
+    }
+    st16<T>(dg + row * lddg + c0, og);
+    st16<T>(dx + row * lddx + c0, ox);
+  }
+};
+
+extern "C" int mi355_gate_bn_bwd_reduce_rows(long long M) { return rowred_grid<GateBnBwdReduceOp<bf16_t>>(M); }
+
+template <typename T, typename Op> static void fill_gate_bn(Op& op, const float* dz, const void* g1, int ldg, const void* x1, int ldx,
+                                                            const float* const* co, const float* w) {
+  op.dz = dz; op.g1 = (const T*)g1; op.ldg = ldg; op.x1 = (const T*)x1; op.ldx = ldx;
+  op.scale_g = co[0]; op.shift_g = co[1]; op.mean_g = co[2]; op.invstd_g = co[3];
+  op.scale_x = co[4]; op.shift_x = co[5]; op.mean_x = co[6]; op.invstd_x = co[7];
+  op.w = w;
+}
+
+extern "C" int mi355_gate_bn_bwd_reduce(const float* dz, const void* g1, int ldg, const void* x1, int ldx, const float* scale_g,
+                                        const float* shift_g, const float* mean_g, const float* invstd_g, const float* scale_x,
+                                        const float* shift_x, const float* mean_x, const float* invstd_x, const float* w,
+                                        float* partial, long long M, int C, int dtype, mi355_stream_t s) {
+  MI355_CHECK_ARG(dz && g1 && x1 && scale_g && shift_g && mean_g && invstd_g && scale_x && shift_x && mean_x && invstd_x && w && partial,
+                  "gate_bn_bwd_reduce: null pointer");
+  const float* co[8] = {scale_g, shift_g, mean_g, invstd_g, scale_x, shift_x, mean_x, invstd_x};
+  return dispatch_dtype(dtype, "gate_bn_bwd_reduce", [&](auto tag) {
+    using T = decltype(tag);
+    GateBnBwdReduceOp<T> op;
+    fill_gate_bn<T>(op, dz, g1, ldg, x1, ldx, co, w);
+    return rowred_launch<T>(op, M, C, partial, (hipStream_t)s);
+  });
+}
+
+extern "C" int mi355_gate_bn_bwd_apply(const float* dz, const void* g1, int ldg, const void* x1, int ldx, const float* scale_g,
+                                       const float* shift_g, const float* mean_g, const float* invstd_g, const float* scale_x,
+                                       const float* shift_x, const float* mean_x, const float* invstd_x, const float* w,
+                                       const float* gamma_g, const float* gamma_x, const float* sums_g, const float* sums_x,
+                                       void* dg1, int lddg, void* dx1, int lddx, long long M, int C, int dtype, mi355_stream_t s) {
+  MI355_CHECK_ARG(dz && g1 && x1 && scale_g && shift_g && mean_g && invstd_g && scale_x && shift_x && mean_x && invstd_x && w &&
+                  gamma_g && gamma_x && sums_g && sums_x && dg1 && dx1, "gate_bn_bwd_apply: null pointer");
+  const float* co[8] = {scale_g, shift_g, mean_g, invstd_g, scale_x, shift_x, mean_x, invstd_x};
+  return dispatch_dtype(dtype, "gate_bn_bwd_apply", [&](auto tag) {
+    using T = decltype(tag);
+    GateBnBwdApplyOp<T> op;
+    fill_gate_bn<T>(op, dz, g1, ldg, x1, ldx, co, w);
+    op.gamma_g = gamma_g; op.gamma_x = gamma_x; op.sums_g = sums_g; op.sums_x = sums_x;
+    op.dg = (T*)dg1; op.lddg = lddg; op.dx = (T*)dx1; op.lddx = lddx; op.invM = (float)(1.0 / (double)M); op.C = C;
+    return rowred_launch<T>(op, M, C, nullptr, (hipStream_t)s);
+  });
+}
+
 // ---- x * sigmoid(bn1(z)) ---------------------------------------------------------------------------------
 template <typename T> struct GateMulOp {
   static constexpr int EPC = 16 / (int)sizeof(T);

@@ -28,6 +28,7 @@ BN_EPS_DEFAULT = 1e-5
 CPAD = 32          # network inputs are zero-padded to 32 channels (MFMA K granularity)
 FUSE_POOL = os.environ.get("MI355_FUSE_POOL", "1") != "0"      # MaxPool2d(2, 2) inside the BatchNorm apply pass that feeds it (A/B switch)
 FUSE_POOL_BWD = os.environ.get("MI355_FUSE_POOL_BWD", "1") != "0"   # ... and its gradient inside that layer's two BatchNorm backward passes
+FUSE_GATE_BWD = os.environ.get("MI355_FUSE_GATE_BWD", "1") != "0"   # attention gate: both branches' BatchNorm backward in two passes, d(psi_in) never stored
 FUSE_RESIDUAL = os.environ.get("MI355_FUSE_RESIDUAL", "1") != "0"   # RRCNN_block's x0 + RCNN(x0) inside the last BatchNorm apply pass (A/B switch)
 
 
@@ -953,13 +954,43 @@ class Builder:
             self.bwd.append(Launch("mi355_bn_bwd_finalize", part2, nb, 1, sums, gref, bref, gbeta))
             dz = self.f32(M)
             self.bwd.append(Launch("mi355_bn1_bwd_apply", dzn, z, bp.weight, sp["mean"], sp["invstd"], sums, dz, M))
+            wref, wbeta = self.pgrad(cp.weight)
+            bref2, bbeta = self.pgrad(cp.bias)
+            if FUSE_GATE_BWD:
+                # psi conv (F_int -> 1) and the two normalised branches in two passes: dp = dz * w masked by p > 0 is recomputed from
+                # the raw branch outputs where it is needed (mi355_rowdot_bwd would write it, four BatchNorm passes read it)
+                part3 = self.ws_f32(nb * 5 * F_int)
+                co = (sg["scale"], sg["shift"], sg["mean"], sg["invstd"], sx["scale"], sx["shift"], sx["mean"], sx["invstd"])
+                self.bwd.append(Launch("mi355_gate_bn_bwd_reduce", dz, g1, g1.ld, x1, x1.ld, *co, cp.weight, part3, M, F_int, self.code,
+                                       nbytes=2 * M * F_int * self.esz + 4 * M))
+                self.bwd.append(Launch("mi355_colsum_finalize", self._ws_off(part3, 3 * F_int * 4), nb, 5, F_int, wref, wbeta))
+                self.bwd.append(Launch("mi355_colsum_finalize", self._ws_off(part3, 4 * F_int * 4), nb, 5 * F_int, 1, bref2, bbeta))
+                nbf = min(nb, lib.mi355_gate_bn_bwd_reduce_rows(M))
+                sums = []
+                for q1, bn_, bias_ in ((1, bg, cg.bias), (2, bx, cx.bias)):
+                    sm = self.f32(2 * F_int)
+                    need_pg = bn_.weight.requires_grad
+                    if need_pg:
+                        gref_, gbeta_ = self.pgrad(bn_.weight)
+                        bref_, _ = self.pgrad(bn_.bias)
+                    self.bwd.append(Launch("mi355_bn_bwd_finalize_at", part3, nbf, 5, 0, q1, F_int, sm, gref_ if need_pg else None,
+                                           bref_ if need_pg else None, gbeta_ if need_pg else 0.0))
+                    if bias_ is not None and bias_.requires_grad and id(bias_) not in self._grad_first:      # (see _bn_bwd)
+                        self.pgrad(bias_)
+                        self.zero_grad_params.append(bias_)
+                    sums.append(sm)
+                dg1, dx1 = self.grad_of(g1), self.grad_of(x1)
+                self.bwd.append(Launch("mi355_gate_bn_bwd_apply", dz, g1, g1.ld, x1, x1.ld, *co, cp.weight, bg.weight, bx.weight,
+                                       sums[0], sums[1], dg1, dg1.ld, dx1, dx1.ld, M, F_int, self.code,
+                                       nbytes=4 * M * F_int * self.esz + 4 * M))
+                g1_bwd(dg1, bias_done=True)
+                x1_bwd(dx1, bias_done=True)
+                return
             # psi conv (F_int -> 1): dp = dz*w masked by p>0, dw, db
             dp = self.new_tensor(x.N, x.H, x.W, F_int)
             part3 = self.ws_f32(nb * 2 * F_int)
             self.bwd.append(Launch("mi355_rowdot_bwd", dz, p, p.ld, cp.weight, dp, dp.ld, part3, M, F_int, 1, 0, 1, 0, self.code))
-            wref, wbeta = self.pgrad(cp.weight)
             self.bwd.append(Launch("mi355_colsum_finalize", part3, nb, 2, F_int, wref, wbeta))
-            bref2, bbeta = self.pgrad(cp.bias)
             self.bwd.append(Launch("mi355_colsum_finalize", self._ws_off(part3, F_int * 4), nb, 2 * F_int, 1, bref2, bbeta))
             # the two normalised branches share dp
             dg1 = self._bn_bwd(dp, None, g1, bg, sg, False, bias=cg.bias)

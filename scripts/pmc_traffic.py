@@ -35,7 +35,8 @@ def demangle(name):
 # streaming kernels are templates over an Op type: bench.py tags them by their launcher
 OP_TAGS = (("BnBwdReduceOp", "mi355_bn_bwd_reduce"), ("BnBwdApplyOp", "mi355_bn_bwd_apply"), ("BnActOp", "mi355_bn_act"),
            ("bn_act_pool2_kernel", "mi355_bn_act_pool2"), ("BnStatsOp", "mi355_bn_stats"),
-           ("BnBwdReducePool2Op", "mi355_bn_bwd_reduce_pool2"), ("BnBwdApplyPool2Op", "mi355_bn_bwd_apply_pool2"))
+           ("BnBwdReducePool2Op", "mi355_bn_bwd_reduce_pool2"), ("BnBwdApplyPool2Op", "mi355_bn_bwd_apply_pool2"),
+           ("GateBnBwdReduceOp", "mi355_gate_bn_bwd_reduce"), ("GateBnBwdApplyOp", "mi355_gate_bn_bwd_apply"))
 
 
 def per_kernel(pattern, counter):

@@ -254,6 +254,88 @@ def test_bn_backward_with_lazy_maxpool_gradient(shape, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(2, 32, 16, 24), (1, 64, 8, 8), (3, 256, 5, 4)])
+def test_gate_branches_backward_in_two_passes(shape, dtype):
+    """mi355_gate_bn_bwd_reduce / _apply (+ mi355_bn_bwd_finalize_at, mi355_colsum_finalize): the backward of
+    psi_in = relu(BN_g(g1) + BN_x(x1)), z = psi conv (AttentionUNet.py:32-38,48-52) without the stored gradient of psi_in, against
+    the separate passes (mi355_rowdot_bwd + two BatchNorm backward chains) and against torch autograd on the CPU."""
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(c + h)
+    code = DTYPE_CODE[dtype]
+    m = n * h * w
+    g1 = q(torch.randn(n, c, h, w, generator=g) * 1.5 + 0.3, dtype)
+    x1 = q(torch.randn(n, c, h, w, generator=g) - 0.2, dtype)
+    dz = torch.randn(m, generator=g)
+    wpsi = torch.randn(c, generator=g) * 0.5
+    gam = [torch.rand(c, generator=g) + 0.5 for _ in range(2)]
+    bet = [torch.randn(c, generator=g) * 0.3 for _ in range(2)]
+    co = []
+    for t, ga, be in ((g1, gam[0], bet[0]), (x1, gam[1], bet[1])):
+        mean = t.mean((0, 2, 3)); invstd = (t.var((0, 2, 3), unbiased=False) + 1e-5).rsqrt()
+        co += [ga * invstd, be - mean * ga * invstd, mean, invstd]
+    D = [dev(t.float().contiguous()) for t in co]
+    g1d, x1d = to_nhwc(g1, dtype), to_nhwc(x1, dtype)
+    dzd, wd = dev(dz), dev(wpsi)
+    gd = [dev(t) for t in gam]
+    nb = lib.mi355_rowreduce_blocks(m)
+    res = []
+    for fused in (0, 1):
+        dg = torch.zeros(n, h, w, c + 8, dtype=dtype, device=DEV)
+        dx = torch.zeros(n, h, w, c, dtype=dtype, device=DEV)
+        es = dg.element_size()
+        dw = torch.empty(c, device=DEV); db = torch.empty(1, device=DEV)
+        sm = [torch.empty(2 * c, device=DEV) for _ in range(2)]
+        dga = [torch.empty(c, device=DEV) for _ in range(2)]; dbe = [torch.empty(c, device=DEV) for _ in range(2)]
+        if fused:
+            part = torch.full((nb * 5 * c,), float("nan"), device=DEV)
+            lib.mi355_gate_bn_bwd_reduce(dzd, g1d, c, x1d, c, *D, wd, part, m, c, code)
+            lib.mi355_colsum_finalize(part.data_ptr() + 3 * c * 4, nb, 5, c, dw, 0.0)
+            lib.mi355_colsum_finalize(part.data_ptr() + 4 * c * 4, nb, 5 * c, 1, db, 0.0)
+            nbf = min(nb, lib.mi355_gate_bn_bwd_reduce_rows(m))
+            for i in range(2):
+                lib.mi355_bn_bwd_finalize_at(part, nbf, 5, 0, 1 + i, c, sm[i], dga[i], dbe[i], 0.0)
+            lib.mi355_gate_bn_bwd_apply(dzd, g1d, c, x1d, c, *D, wd, gd[0], gd[1], sm[0], sm[1], dg.data_ptr() + 8 * es, c + 8, dx, c, m, c, code)
+        else:
+            p = torch.empty(n, h, w, c, dtype=dtype, device=DEV)
+            lib.mi355_bn_act(g1d, c, D[0], D[1], x1d, c, D[4], D[5], None, 0, p, c, m, c, 1, code)
+            dp = torch.empty_like(p)
+            part = torch.full((nb * 2 * c,), float("nan"), device=DEV)
+            lib.mi355_rowdot_bwd(dzd, p, c, wd, dp, c, part, m, c, 1, 0, 1, 0, code)
+            lib.mi355_colsum_finalize(part, nb, 2, c, dw, 0.0)
+            lib.mi355_colsum_finalize(part.data_ptr() + c * 4, nb, 2 * c, 1, db, 0.0)
+            for i, (t, out, ld) in enumerate(((g1d, dg.data_ptr() + 8 * es, c + 8), (x1d, dx, c))):
+                part2 = torch.full((nb * 2 * c,), float("nan"), device=DEV)
+                lib.mi355_bn_bwd_reduce(dp, c, None, 0, t, c, D[4 * i + 2], D[4 * i + 3], D[4 * i], D[4 * i + 1], part2, m, c, 0, code)
+                lib.mi355_bn_bwd_finalize(part2, min(nb, lib.mi355_bn_bwd_reduce_rows(m)), c, sm[i], dga[i], dbe[i], 0.0)
+                lib.mi355_bn_bwd_apply(dp, c, None, 0, t, c, gd[i], D[4 * i + 2], D[4 * i + 3], D[4 * i], D[4 * i + 1], sm[i], out, ld,
+                                       None, 0, None, 0, 0, None, m, c, 0, code)
+        torch.cuda.synchronize()
+        assert float(dg[..., :8].abs().sum()) == 0
+        res.append([from_nhwc(dg[..., 8:].float().cpu()), from_nhwc(dx.float().cpu()), dw.cpu(), db.cpu(), dga[0].cpu(), dbe[0].cpu(),
+                    dga[1].cpu(), dbe[1].cpu()])
+    # torch: autograd through both BatchNorms (batch statistics), the sum, the ReLU and the one-channel convolution
+    leaves = [t.clone().requires_grad_(True) for t in (g1, x1, wpsi, torch.zeros(1), gam[0], bet[0], gam[1], bet[1])]
+    a = F.batch_norm(leaves[0], None, None, leaves[4], leaves[5], True, 0.1, 1e-5) + \
+        F.batch_norm(leaves[1], None, None, leaves[6], leaves[7], True, 0.1, 1e-5)
+    pr = F.relu(a)
+    z = (q(pr.detach(), dtype) + (pr - pr.detach())).permute(0, 2, 3, 1).reshape(m, c) @ leaves[2] + leaves[3]
+    (z * dz).sum().backward()
+    ref = [l.grad for l in leaves]
+    tol = TOL[dtype] if dtype != torch.float32 else 1e-4
+    for i in range(8):
+        for r in res:
+            assert rel_err(r[i], ref[i]) < 2 * tol, (i, rel_err(r[i], ref[i]))
+        # the gradient of psi_in is rounded to the storage type exactly as the separate pass stores it: the branch gradients and
+        # the BatchNorm parameter gradients are the SAME numbers (same row order, same arithmetic); the psi weight's gradient is
+        # summed over another grid
+        # (fp32 and bf16; the fp16 instantiations of the two kernel families contract the apply arithmetic differently)
+        if i in (0, 1, 4, 5, 6, 7) and dtype != torch.float16:
+            assert torch.equal(res[1][i], res[0][i]), i
+        else:
+            assert rel_err(res[1][i], res[0][i]) < (2e-5 if i in (2, 3) or dtype == torch.float32 else tol), i
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_upsample_bwd_add_relu(dtype):
     n, c, h, w = 2, 32, 5, 7
     g = torch.Generator().manual_seed(9)

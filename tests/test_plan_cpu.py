@@ -52,7 +52,7 @@ def test_plan_structure(name):
     for l in plan.bwd:
         for i, a in enumerate(l.args):
             if isinstance(a, graph.GRef):
-                beta = l.args[-1] if l.name in ("mi355_conv2d_wgrad_reduce", "mi355_colsum_finalize", "mi355_bn_bwd_finalize") else \
+                beta = l.args[-1] if l.name in ("mi355_conv2d_wgrad_reduce", "mi355_colsum_finalize", "mi355_bn_bwd_finalize", "mi355_bn_bwd_finalize_at") else \
                     (l.args[-2] if l.name == "mi355_linear_bwd" else None)          # (..., beta, scratch)
                 assert beta is not None, l.name
                 d = first if beta == 0.0 else later

@@ -253,6 +253,13 @@ int mi355_gate_mul_bwd(const void* dy, int lddy, const void* x, int ldx, const f
 /* scalar-field BN backward: dz = gamma*invstd*(dzn - S0/M - zhat*S1/M). */
 int mi355_bn1_bwd_apply(const float* dzn, const float* z, const float* gamma, const float* mean,
                         const float* invstd, const float* sums, float* dz, long long M, mi355_stream_t s);
+/* psi_in = relu(BN_g(g1) + BN_x(x1)) and z = psi conv of it in ONE pass over the raw branch outputs (instead of mi355_bn_act with a
+ * second operand + mi355_rowdot_fwd): psi_in is computed as mi355_bn_act would have stored it and is not stored — the backward
+ * below recomputes it as well.  partial: per-block (sum z, sum z^2) or null.  _ok: C / (16 / element size) <= 64. */
+int mi355_gate_psi_fwd_ok(int C, int dtype);
+int mi355_gate_psi_fwd(const void* g1, int ldg, const void* x1, int ldx, const float* scale_g, const float* shift_g,
+                       const float* scale_x, const float* shift_x, const float* w, const float* b, float* z,
+                       float* partial, long long M, int C, int dtype, mi355_stream_t s);
 /* Backward of the gate's two normalised branches in two passes instead of mi355_rowdot_bwd + 2 x (mi355_bn_bwd_reduce,
  * mi355_bn_bwd_apply) (AttentionUNet.py:32-38,48-52: psi_in = relu(BN_g(W_g g) + BN_x(W_x x)), z = psi conv).  g1 / x1 are the RAW
  * branch convolution outputs, scale / shift / mean / invstd the forward's coefficients of the two BatchNorms, w the psi

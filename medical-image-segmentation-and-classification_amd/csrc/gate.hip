@@ -151,6 +151,91 @@ extern "C" int mi355_rowdot_bwd(const float* dz, const void* x, int ldx, const f
   });
 }
 
+// ---- psi_in = relu(BN_g(g1) + BN_x(x1)) and the one-channel psi convolution in one pass (AttentionUNet.py:48-52) --------------
+// z[m] = b + sum_c w[c] * psi_in[m][c] with psi_in computed from the raw branch outputs as mi355_bn_act would have stored it
+// (same fmaf chain, rounded to the storage type) — and NOT stored: the backward (mi355_gate_bn_bwd_*) recomputes it too.  The
+// dot product sums in mi355_rowdot_fwd's order.  Four rows per lane group are in flight (two 16-byte loads each).
+template <typename T>
+__global__ __launch_bounds__(256) void gate_psi_fwd_kernel(const T* __restrict__ g1, int ldg, const T* __restrict__ x1, int ldx,
+                                                           const float* __restrict__ scale_g, const float* __restrict__ shift_g,
+                                                           const float* __restrict__ scale_x, const float* __restrict__ shift_x,
+                                                           const float* __restrict__ w, const float* __restrict__ b,
+                                                           float* __restrict__ z, float* __restrict__ partial, long long M, int C,
+                                                           int rows_per_block, int tpr) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int U = 4;
+  const int cp = C / EPC;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % tpr, rsub = lane / tpr, rpw = 64 / tpr;
+  const bool on = sub < cp;
+  float sg[EPC], sx[EPC], sh[EPC], wr[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    sg[e] = on ? scale_g[sub * EPC + e] : 0.f;
+    sx[e] = on ? scale_x[sub * EPC + e] : 0.f;
+    sh[e] = on ? shift_g[sub * EPC + e] + shift_x[sub * EPC + e] : 0.f;
+    wr[e] = on ? w[sub * EPC + e] : 0.f;
+  }
+  const float bias = b ? b[0] : 0.f;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = min(M, r0 + rows_per_block);
+  double s0 = 0, s1 = 0;
+  for (long long base = r0 + wave * rpw; base < r1; base += (long long)U * 4 * rpw) {
+    Vec16<T> gv[U], xv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long r = base + (long long)u * 4 * rpw + rsub;
+      if (r < r1 && on) {
+        gv[u] = ld16<T>(g1 + (size_t)r * ldg + sub * EPC);
+        xv[u] = ld16<T>(x1 + (size_t)r * ldx + sub * EPC);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long r = base + (long long)u * 4 * rpw + rsub;
+      float acc = 0.f;
+      if (r < r1 && on) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          const float f = __builtin_fmaf(to_f32<T>(xv[u].v[e]), sx[e], __builtin_fmaf(to_f32<T>(gv[u].v[e]), sg[e], sh[e]));
+          acc += to_f32<T>(from_f32<T>(fmaxf(f, 0.f))) * wr[e];
+        }
+      }
+      acc = seg_sum(acc, tpr);
+      if (r < r1 && sub == 0) {
+        const float zz = acc + bias;
+        z[r] = zz;
+        s0 += zz;
+        s1 += (double)zz * zz;
+      }
+    }
+  }
+  block_pair_sum(s0, s1, partial);
+}
+
+extern "C" int mi355_gate_psi_fwd_ok(int C, int dtype) {
+  const int epc = dtype_is_2byte(dtype) ? 8 : 4;
+  return C % epc == 0 && C / epc <= 64;
+}
+
+extern "C" int mi355_gate_psi_fwd(const void* g1, int ldg, const void* x1, int ldx, const float* scale_g, const float* shift_g,
+                                  const float* scale_x, const float* shift_x, const float* w, const float* b, float* z,
+                                  float* partial, long long M, int C, int dtype, mi355_stream_t s) {
+  MI355_CHECK_ARG(g1 && x1 && scale_g && shift_g && scale_x && shift_x && w && z, "gate_psi_fwd: null pointer");
+  MI355_CHECK_ARG(mi355_gate_psi_fwd_ok(C, dtype), "gate_psi_fwd: unsupported C=%d", C);
+  const int epc = dtype_is_2byte(dtype) ? 8 : 4;
+  const int nb = rowreduce_blocks(M);
+  const int rpb = (int)((M + nb - 1) / nb);
+  const int tpr = pow2_tpr(C / epc);
+  return dispatch_dtype(dtype, "gate_psi_fwd", [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((gate_psi_fwd_kernel<T>), dim3(nb), dim3(256), 0, (hipStream_t)s, (const T*)g1, ldg, (const T*)x1, ldx, scale_g,
+                       shift_g, scale_x, shift_x, w, b, z, partial, M, C, rpb, tpr);
+    MI355_LAUNCH_CHECK();
+    return (int)MI355_OK;
+  });
+}
+
 // ---- backward of the gate's two normalised branches, W_g / W_x (AttentionUNet.py:32-38,48-52) ---------------------------------
 // p = relu(bn_g(g1) + bn_x(x1)) feeds the one-channel psi convolution; given dz (the gradient of that convolution's output) the
 // gradient of p is dz[m] * w[c] where p > 0 — a tensor mi355_rowdot_bwd would write and FOUR BatchNorm passes (two branches x

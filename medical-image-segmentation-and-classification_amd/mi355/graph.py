@@ -328,7 +328,8 @@ class Builder:
         self.output = None
         self.dout = None
         self.bn_momentum = 0.1
-        self.acts = []                   # ("relu", a) | ("relu_pre", y, scale, shift) | ("relu_v", y) | ("pool", x, y, k, s, p) | ("gmax", x, argmax)
+        # ("relu", a) | ("relu_pre", y, scale, shift) | ("relu_pre2", g1, scale, shift, x1, scale, shift) | ("relu_v", y) | ("pool", x, y, k, s, p) | ("gmax", x, argmax)
+        self.acts = []
 
     # ---- allocation ---------------------------------------------------------------------------
     def _alloc(self, numel, dtype=None):
@@ -909,24 +910,40 @@ class Builder:
         sg = self._bn_coeffs(g1, bg, self._last_stat_rows)
         x1, x1_bwd = self.conv_raw(x, cx, stats=True)
         sx = self._bn_coeffs(x1, bx, self._last_stat_rows)
-        p = self.new_tensor(x.N, x.H, x.W, F_int)
-        self.fwd.append(Launch("mi355_bn_act", g1, g1.ld, sg["scale"], sg["shift"], x1, x1.ld, sx["scale"], sx["shift"],
-                               None, 0, p, p.ld, M, F_int, 1, self.code))
-        self.acts.append(("relu", p))
+        # psi_in = relu(bn(g1) + bn(x1)) is not materialised when both directions recompute it from the raw branch outputs
+        fused = FUSE_GATE_BWD and bool(lib.mi355_gate_psi_fwd_ok(F_int, self.code))
         z = self.f32(M)
         nb = lib.mi355_rowreduce_blocks(M)
+
+        def psi_fwd(part):
+            self.fwd.append(Launch("mi355_gate_psi_fwd", g1, g1.ld, x1, x1.ld, sg["scale"], sg["shift"], sx["scale"], sx["shift"],
+                                   cp.weight, cp.bias, z, part, M, F_int, self.code, nbytes=2 * M * F_int * self.esz + 4 * M))
+        if fused:
+            p = None
+            self.acts.append(("relu_pre2", g1, sg["scale"], sg["shift"], x1, sx["scale"], sx["shift"]))
+        else:
+            p = self.new_tensor(x.N, x.H, x.W, F_int)
+            self.fwd.append(Launch("mi355_bn_act", g1, g1.ld, sg["scale"], sg["shift"], x1, x1.ld, sx["scale"], sx["shift"],
+                                   None, 0, p, p.ld, M, F_int, 1, self.code))
+            self.acts.append(("relu", p))
         sp = {k: self.f32(1) for k in ("scale", "shift", "mean", "invstd")}
         self.see(cp.weight, cp.bias, bp.weight, bp.bias)
         if self.training:
             part = self.ws_f32(nb * 2)
-            self.fwd.append(Launch("mi355_rowdot_fwd", p, p.ld, cp.weight, cp.bias, z, part, M, F_int, 0, 1, self.code))
+            if fused:
+                psi_fwd(part)
+            else:
+                self.fwd.append(Launch("mi355_rowdot_fwd", p, p.ld, cp.weight, cp.bias, z, part, M, F_int, 0, 1, self.code))
             track = bp.track_running_stats
             self.fwd.append(Launch("mi355_bn_finalize", part, nb, M, 1, bp.weight, bp.bias,
                                    bp.running_mean if track else None, bp.running_var if track else None,
                                    bp.num_batches_tracked if track else None, float(bp.momentum or 0.1), float(bp.eps),
                                    sp["scale"], sp["shift"], sp["mean"], sp["invstd"]))
         else:
-            self.fwd.append(Launch("mi355_rowdot_fwd", p, p.ld, cp.weight, cp.bias, z, None, M, F_int, 0, 1, self.code))
+            if fused:
+                psi_fwd(None)
+            else:
+                self.fwd.append(Launch("mi355_rowdot_fwd", p, p.ld, cp.weight, cp.bias, z, None, M, F_int, 0, 1, self.code))
             self.fwd.append(Launch("mi355_bn_eval_coeffs", bp.weight, bp.bias, bp.running_mean, bp.running_var, float(bp.eps), 1,
                                    sp["scale"], sp["shift"]))
         y = out if out is not None else self.new_tensor(x.N, x.H, x.W, x.C)
@@ -956,7 +973,7 @@ class Builder:
             self.bwd.append(Launch("mi355_bn1_bwd_apply", dzn, z, bp.weight, sp["mean"], sp["invstd"], sums, dz, M))
             wref, wbeta = self.pgrad(cp.weight)
             bref2, bbeta = self.pgrad(cp.bias)
-            if FUSE_GATE_BWD:
+            if fused:
                 # psi conv (F_int -> 1) and the two normalised branches in two passes: dp = dz * w masked by p > 0 is recomputed from
                 # the raw branch outputs where it is needed (mi355_rowdot_bwd would write it, four BatchNorm passes read it)
                 part3 = self.ws_f32(nb * 5 * F_int)

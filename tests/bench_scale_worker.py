@@ -103,7 +103,8 @@ def run(cfg, dtype, x, y):
     torch.cuda.synchronize()
     m.engine.flat_g.mul_(1.0 / scale)
     plan = out._mi355_plan
-    kept = [a[1] for a in plan.acts if a[0] in ("relu", "relu_pre")]      # (relu_pre: the raw convolution output of a recurrent application)
+    # (relu_pre: the raw convolution output of a recurrent application; relu_pre2: the raw W_g output of an attention gate)
+    kept = [a[1] for a in plan.acts if a[0] in ("relu", "relu_pre", "relu_pre2")]
     kept = kept[::max(1, -(-len(kept) // MAX_ACTS))]
     acts = [a.torch_view().float().clone() for a in kept]
     trainable = [p for _, p in m.named_parameters() if p.requires_grad]

@@ -57,6 +57,12 @@ def gpu_kinks(plan):
             y, sc, sh = a[1], a[2], a[3]
             v = torch.addcmul(sh[: y.C].view(1, 1, 1, -1), y.torch_view().float(), sc[: y.C].view(1, 1, 1, -1))
             relu.append((v > 0).permute(0, 3, 1, 2).contiguous().cpu())
+        elif a[0] == "relu_pre2":                 # attention gate: relu(bn(g1) + bn(x1)) is never stored (mi355_gate_psi_fwd)
+            g1, sg, tg, x1, sx, tx = a[1:]
+            c = g1.C
+            v = torch.addcmul((tg[:c] + tx[:c]).view(1, 1, 1, -1), g1.torch_view().float(), sg[:c].view(1, 1, 1, -1))
+            v = torch.addcmul(v, x1.torch_view().float(), sx[:c].view(1, 1, 1, -1))
+            relu.append((v > 0).permute(0, 3, 1, 2).contiguous().cpu())
         elif a[0] == "relu_v":                    # ReLU behind a Linear of a classifier head: fp32 [B, F]
             y = a[1]
             relu.append((y.buf[: y.B * y.F].view(y.B, y.F) > 0).cpu())

@@ -286,7 +286,10 @@ def test_gate_branches_backward_in_two_passes(shape, dtype):
         dw = torch.empty(c, device=DEV); db = torch.empty(1, device=DEV)
         sm = [torch.empty(2 * c, device=DEV) for _ in range(2)]
         dga = [torch.empty(c, device=DEV) for _ in range(2)]; dbe = [torch.empty(c, device=DEV) for _ in range(2)]
+        zz = torch.empty(m, device=DEV); zp = torch.full((nb * 2,), float("nan"), device=DEV)
+        bpsi = dev(torch.tensor([0.37]))
         if fused:
+            lib.mi355_gate_psi_fwd(g1d, c, x1d, c, D[0], D[1], D[4], D[5], wd, bpsi, zz, zp, m, c, code)
             part = torch.full((nb * 5 * c,), float("nan"), device=DEV)
             lib.mi355_gate_bn_bwd_reduce(dzd, g1d, c, x1d, c, *D, wd, part, m, c, code)
             lib.mi355_colsum_finalize(part.data_ptr() + 3 * c * 4, nb, 5, c, dw, 0.0)
@@ -298,6 +301,7 @@ def test_gate_branches_backward_in_two_passes(shape, dtype):
         else:
             p = torch.empty(n, h, w, c, dtype=dtype, device=DEV)
             lib.mi355_bn_act(g1d, c, D[0], D[1], x1d, c, D[4], D[5], None, 0, p, c, m, c, 1, code)
+            lib.mi355_rowdot_fwd(p, c, wd, bpsi, zz, zp, m, c, 0, 1, code)
             dp = torch.empty_like(p)
             part = torch.full((nb * 2 * c,), float("nan"), device=DEV)
             lib.mi355_rowdot_bwd(dzd, p, c, wd, dp, c, part, m, c, 1, 0, 1, 0, code)
@@ -312,7 +316,10 @@ def test_gate_branches_backward_in_two_passes(shape, dtype):
         torch.cuda.synchronize()
         assert float(dg[..., :8].abs().sum()) == 0
         res.append([from_nhwc(dg[..., 8:].float().cpu()), from_nhwc(dx.float().cpu()), dw.cpu(), db.cpu(), dga[0].cpu(), dbe[0].cpu(),
-                    dga[1].cpu(), dbe[1].cpu()])
+                    dga[1].cpu(), dbe[1].cpu(), zz.cpu(), zp.cpu()])
+    # the forward: z and its (sum, sum of squares) partials from one pass as from two — to the last bits (the compiler fuses the
+    # multiply-adds of the dot product in one kernel and not in the other)
+    assert rel_err(res[1][8], res[0][8]) < 1e-6 and rel_err(res[1][9], res[0][9]) < 1e-6
     # torch: autograd through both BatchNorms (batch statistics), the sum, the ReLU and the one-channel convolution
     leaves = [t.clone().requires_grad_(True) for t in (g1, x1, wpsi, torch.zeros(1), gam[0], bet[0], gam[1], bet[1])]
     a = F.batch_norm(leaves[0], None, None, leaves[4], leaves[5], True, 0.1, 1e-5) + \
@@ -320,6 +327,7 @@ def test_gate_branches_backward_in_two_passes(shape, dtype):
     pr = F.relu(a)
     z = (q(pr.detach(), dtype) + (pr - pr.detach())).permute(0, 2, 3, 1).reshape(m, c) @ leaves[2] + leaves[3]
     (z * dz).sum().backward()
+    assert rel_err(res[1][8], z.detach() + 0.37) < 2 * (TOL[dtype] if dtype != torch.float32 else 1e-5)
     ref = [l.grad for l in leaves]
     tol = TOL[dtype] if dtype != torch.float32 else 1e-4
     for i in range(8):

@@ -5,8 +5,15 @@ BCEWithLogits, clip 1.0, AdamW wd 5e-4) —
 and compare the Dice of the binarised predictions (tester.py:114-134) on 32 held-out images.
 Bound: |Dice - Dice_oracle| <= 1e-3 (0..1 scale) for every GPU mode; final losses within 2 %.
 
-R2AttU_Net (R2AttU_Net.py:88-158, config C4: bf16) runs the same protocol for 32 steps with the same 1e-3 bound on Dice.  Why
-32: with 108 shared-weight convolutions per forward the early trajectory is chaotic ON THE CPU ALONE — tests/diag/diag_r2_chaos.py
+R2AttU_Net (R2AttU_Net.py:88-158, config C4: bf16) runs the same protocol for 32 steps; fp32 with the same 1e-3 bound on Dice,
+bf16 with 3e-3 — the spread of EQUALLY VALID bf16 arithmetic: tests/diag/diag_r2_bf16_spread.py trains the HIP path once per
+combination of the plan-level fusion switches (the same function, bf16 roundings in different places: a gradient rounded before or
+after a sum, a dot product with or without a fused multiply-add).  In fp32 all combinations are bit-identical (Dice 0.99088 at
+step 32, oracle 0.99080); in bf16 they are 2.5e-3 apart at step 32 (0.99045 .. 0.99291), 0.75e-3 at steps 48 and 64, 2.2e-3 at
+80, and the fp32 trajectory itself moves by 3e-3 from one mark to the next (profiles/r03c_r2attunet_bf16_dice_spread.txt).  A
+1e-3 bound on ONE bf16 trajectory of this network is met or missed by rounding placement, not by correctness (it held in round 3
+until a dot product gained a fused multiply-add), so it is asserted where it is a statement about arithmetic: fp32 training,
+and the oracle-trained weights through the bf16 forward.  Why 32 steps: with 108 shared-weight convolutions per forward the early trajectory is chaotic ON THE CPU ALONE — tests/diag/diag_r2_chaos.py
 runs this protocol four ways that differ only in summation order / precision (fp32 with 8 threads, 1 thread, the batch reversed;
 fp64) and those runs are 3.9e-3 apart in Dice at step 8, 1.9e-3 at step 12, 2.4e-4 at step 20 and 4.1e-4 at step 32, where Dice
 has reached its plateau (0.9907-0.9911); their last-batch losses stay 8-20 % apart throughout (tests/test_oracle_kinks.py
@@ -57,7 +64,9 @@ def test_dice_after_training_matches_oracle(name, steps, dtypes):
         ref_dice = _dice(fwd({k: v.clone() for k, v in sd.items()}, xv, True), mv)
     assert ref_dice > 0.95          # the task is learnable: the comparison is not degenerate
     strict = name == "AttentionUNet"
-    dice_tol, loss_tol = (1e-3, 0.02) if strict else (1e-3, 0.15)          # (loss: two CPU runs of the R2 protocol are 8-20 % apart, module docstring)
+    loss_tol = 0.02 if strict else 0.15          # (loss: two CPU runs of the R2 protocol are 8-20 % apart, module docstring)
+    # Dice: 1e-3, except a bf16 TRAJECTORY of R2AttU_Net — equally valid bf16 arithmetic is 2.5e-3 apart there (module docstring)
+    dice_tols = {dt: (3e-3 if (not strict and dt == torch.bfloat16) else 1e-3) for dt in dtypes}
 
     # the oracle-trained weights through the HIP forward: Dice within 1e-3 in every precision (no trajectory involved)
     for dtype in dtypes:
@@ -99,5 +108,5 @@ def test_dice_after_training_matches_oracle(name, steps, dtypes):
             assert it == steps
         with torch.no_grad():
             d = _dice(m(xv.to(DEV)).float().cpu(), mv)       # train-mode BN, like the oracle evaluation above
-        assert abs(d - ref_dice) <= dice_tol, (name, str(dtype), d, ref_dice)
+        assert abs(d - ref_dice) <= dice_tols[dtype], (name, str(dtype), d, ref_dice)
         assert abs(float(loss.detach()) - ref_loss) <= loss_tol * ref_loss, (name, str(dtype), float(loss.detach()), ref_loss)

@@ -11,6 +11,12 @@
 
 #define ROWDOT_MAXCH 4
 
+// Workgroups of the moving-window row-dot kernels (the callers size `partial` for rowreduce_blocks(M) rows: the rest is zero-filled)
+static inline int rowdot_grid(int nb) {
+  static const int cap = getenv("MI355_ROWDOT_WGS") ? atoi(getenv("MI355_ROWDOT_WGS")) : 1024;      // (A/B switch)
+  return nb < cap ? nb : cap;
+}
+
 static inline int pow2_tpr(int cp) {
   int t = 1;
   while (t < cp && t < 64) t <<= 1;
@@ -23,7 +29,7 @@ __device__ __forceinline__ float seg_sum(float v, int tpr) {
 }
 
 // block-level sum of two doubles -> partial[blk*2 + {0,1}]
-__device__ __forceinline__ void block_pair_sum(double s0, double s1, float* partial) {
+__device__ __forceinline__ void block_pair_sum(double s0, double s1, float* partial, int nb_rows = 0) {
   __shared__ double red[8];
   s0 = wave_sum_d(s0);
   s1 = wave_sum_d(s1);
@@ -36,6 +42,7 @@ __device__ __forceinline__ void block_pair_sum(double s0, double s1, float* part
   if (threadIdx.x == 0 && partial) {
     partial[blockIdx.x * 2 + 0] = (float)(red[0] + red[2] + red[4] + red[6]);
     partial[blockIdx.x * 2 + 1] = (float)(red[1] + red[3] + red[5] + red[7]);
+    for (int b = blockIdx.x + gridDim.x; b < nb_rows; b += gridDim.x) partial[b * 2] = partial[b * 2 + 1] = 0.f;      // rows past the grid
   }
 }
 
@@ -43,7 +50,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w,
                                                          const float* __restrict__ b, float* __restrict__ z,
                                                          float* __restrict__ partial, long long M, int C,
-                                                         int rows_per_block, int tpr, int hw, int K) {
+                                                         int tpr, int hw, int K, int nb_rows) {
   constexpr int EPC = 16 / (int)sizeof(T);
   const int cp = C / EPC;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -52,36 +59,51 @@ __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const T* __restrict__ x
 #pragma unroll
   for (int k = 0; k < ROWDOT_MAXCH; ++k) {
     const int ck = sub + k * tpr;
+    const int cb = (ck < cp ? ck : 0) * EPC;        // (unconditional loads from a clamped chunk: see gate_psi_fwd_kernel)
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) wr[k][e] = ck < cp ? w[ck * EPC + e] : 0.f;
+    for (int e = 0; e < EPC; ++e) {
+      const float wv = w[cb + e];
+      wr[k][e] = ck < cp ? wv : 0.f;
+    }
   }
   const float bias = b ? b[0] : 0.f;
-  const long long r0 = (long long)blockIdx.x * rows_per_block;
-  const long long r1 = min(M, r0 + rows_per_block);
+  // one moving window over the tensor (see gate_psi_fwd_kernel), U row groups in flight per lane when a row is one chunk per lane
+  constexpr int U = 4;
+  const long long r1 = M;
+  const long long chunk = (long long)U * 4 * rpw;
   double s0 = 0, s1 = 0;
-  for (long long base = r0 + wave * rpw; base < r1; base += 4 * rpw) {
-    const long long r = base + rsub;
-    float acc = 0.f;
-    if (r < r1) {
+  for (long long base = blockIdx.x * chunk + wave * rpw; base < r1; base += (long long)gridDim.x * chunk) {
+    Vec16<T> v0[U];
 #pragma unroll
-      for (int k = 0; k < ROWDOT_MAXCH; ++k) {
-        const int ck = sub + k * tpr;
-        if (ck < cp) {
-          const Vec16<T> v = ld16<T>(x + (size_t)r * ldx + ck * EPC);
+    for (int u = 0; u < U; ++u) {        // (unconditional loads from a clamped (row, chunk): see gate_psi_fwd_kernel)
+      const long long r = base + (long long)u * 4 * rpw + rsub;
+      v0[u] = ld16<T>(x + (size_t)(r < r1 ? r : r1 - 1) * ldx + (sub < cp ? sub : 0) * EPC);
+    }
 #pragma unroll
-          for (int e = 0; e < EPC; ++e) acc += to_f32<T>(v.v[e]) * wr[k][e];
+    for (int u = 0; u < U; ++u) {
+      const long long r = base + (long long)u * 4 * rpw + rsub;
+      float acc = 0.f;
+      if (r < r1) {
+#pragma unroll
+        for (int k = 0; k < ROWDOT_MAXCH; ++k) {
+          const int ck = sub + k * tpr;
+          if (ck < cp) {
+            const Vec16<T> v = k == 0 ? v0[u] : ld16<T>(x + (size_t)r * ldx + ck * EPC);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc += to_f32<T>(v.v[e]) * wr[k][e];
+          }
         }
       }
-    }
-    acc = seg_sum(acc, tpr);
-    if (r < r1 && sub == 0) {
-      const float zz = acc + bias;
-      z[K == 1 ? r : r + (r / hw) * (long long)(K - 1) * hw] = zz;      // K > 1: channel plane of an NCHW [N][K][hw] map
-      s0 += zz;
-      s1 += (double)zz * zz;
+      acc = seg_sum(acc, tpr);
+      if (r < r1 && sub == 0) {
+        const float zz = acc + bias;
+        z[K == 1 ? r : r + (r / hw) * (long long)(K - 1) * hw] = zz;      // K > 1: channel plane of an NCHW [N][K][hw] map
+        s0 += zz;
+        s1 += (double)zz * zz;
+      }
     }
   }
-  block_pair_sum(s0, s1, partial);
+  block_pair_sum(s0, s1, partial, nb_rows);
 }
 
 extern "C" int mi355_rowdot_fwd(const void* x, int ldx, const float* w, const float* b, float* z, float* partial,
@@ -91,12 +113,11 @@ extern "C" int mi355_rowdot_fwd(const void* x, int ldx, const float* w, const fl
   const int epc = dtype_is_2byte(dtype) ? 8 : 4;
   MI355_CHECK_ARG(C % epc == 0 && C / epc <= 64 * ROWDOT_MAXCH, "rowdot_fwd: unsupported C=%d", C);
   const int nb = rowreduce_blocks(M);
-  const int rpb = (int)((M + nb - 1) / nb);
   const int tpr = pow2_tpr(C / epc);
   return dispatch_dtype(dtype, "rowdot_fwd", [&](auto tag) {
     using T = decltype(tag);
-    hipLaunchKernelGGL((rowdot_fwd_kernel<T>), dim3(nb), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx, w, b, z, partial, M, C, rpb,
-                       tpr, HW, K);
+    hipLaunchKernelGGL((rowdot_fwd_kernel<T>), dim3(rowdot_grid(nb)), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx, w, b, z, partial, M, C,
+                       tpr, HW, K, nb);
     MI355_LAUNCH_CHECK();
     return (int)MI355_OK;
   });
@@ -161,45 +182,51 @@ __global__ __launch_bounds__(256) void gate_psi_fwd_kernel(const T* __restrict__
                                                            const float* __restrict__ scale_x, const float* __restrict__ shift_x,
                                                            const float* __restrict__ w, const float* __restrict__ b,
                                                            float* __restrict__ z, float* __restrict__ partial, long long M, int C,
-                                                           int rows_per_block, int tpr) {
+                                                           int tpr, int nb_rows) {
   constexpr int EPC = 16 / (int)sizeof(T);
-  constexpr int U = 4;
+#ifndef GATE_PSI_U
+#define GATE_PSI_U 4
+#endif
+  constexpr int U = GATE_PSI_U;
   const int cp = C / EPC;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % tpr, rsub = lane / tpr, rpw = 64 / tpr;
   const bool on = sub < cp;
+  // per-channel constants: unconditional loads from a clamped chunk (a select per element made the compiler issue 40 dependent
+  // single-dword loads, each waited for: ≈15 us of prologue per launch), lanes past the last chunk zero their weights
   float sg[EPC], sx[EPC], sh[EPC], wr[EPC];
+  const int cb = (on ? sub : 0) * EPC;
 #pragma unroll
   for (int e = 0; e < EPC; ++e) {
-    sg[e] = on ? scale_g[sub * EPC + e] : 0.f;
-    sx[e] = on ? scale_x[sub * EPC + e] : 0.f;
-    sh[e] = on ? shift_g[sub * EPC + e] + shift_x[sub * EPC + e] : 0.f;
-    wr[e] = on ? w[sub * EPC + e] : 0.f;
+    sg[e] = scale_g[cb + e];
+    sx[e] = scale_x[cb + e];
+    sh[e] = shift_g[cb + e] + shift_x[cb + e];
+    const float wv = w[cb + e];
+    wr[e] = on ? wv : 0.f;
   }
   const float bias = b ? b[0] : 0.f;
-  const long long r0 = (long long)blockIdx.x * rows_per_block;
-  const long long r1 = min(M, r0 + rows_per_block);
+  // the grid sweeps the tensor as ONE moving window of gridDim.x chunks of U * 4 * rpw consecutive rows (workgroups that each
+  // stream a far-apart band of their own were 1.3-2x slower: 1024 concurrent DRAM streams)
+  const long long r1 = M;
+  const long long chunk = (long long)U * 4 * rpw;
   double s0 = 0, s1 = 0;
-  for (long long base = r0 + wave * rpw; base < r1; base += (long long)U * 4 * rpw) {
+  for (long long base = blockIdx.x * chunk + wave * rpw; base < r1; base += (long long)gridDim.x * chunk) {
     Vec16<T> gv[U], xv[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < U; ++u) {        // unconditional loads from a clamped (row, chunk): a guarded load is waited for before the next is issued
       const long long r = base + (long long)u * 4 * rpw + rsub;
-      if (r < r1 && on) {
-        gv[u] = ld16<T>(g1 + (size_t)r * ldg + sub * EPC);
-        xv[u] = ld16<T>(x1 + (size_t)r * ldx + sub * EPC);
-      }
+      const size_t rc = (size_t)(r < r1 ? r : r1 - 1);
+      gv[u] = ld16<T>(g1 + rc * ldg + cb);
+      xv[u] = ld16<T>(x1 + rc * ldx + cb);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const long long r = base + (long long)u * 4 * rpw + rsub;
-      float acc = 0.f;
-      if (r < r1 && on) {
+      float acc = 0.f;      // (no guard: lanes past the last chunk carry zero weights, rows past the end are not stored)
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-          const float f = __builtin_fmaf(to_f32<T>(xv[u].v[e]), sx[e], __builtin_fmaf(to_f32<T>(gv[u].v[e]), sg[e], sh[e]));
-          acc += to_f32<T>(from_f32<T>(fmaxf(f, 0.f))) * wr[e];
-        }
+      for (int e = 0; e < EPC; ++e) {
+        const float f = __builtin_fmaf(to_f32<T>(xv[u].v[e]), sx[e], __builtin_fmaf(to_f32<T>(gv[u].v[e]), sg[e], sh[e]));
+        acc += to_f32<T>(from_f32<T>(fmaxf(f, 0.f))) * wr[e];
       }
       acc = seg_sum(acc, tpr);
       if (r < r1 && sub == 0) {
@@ -210,7 +237,7 @@ __global__ __launch_bounds__(256) void gate_psi_fwd_kernel(const T* __restrict__
       }
     }
   }
-  block_pair_sum(s0, s1, partial);
+  block_pair_sum(s0, s1, partial, nb_rows);
 }
 
 extern "C" int mi355_gate_psi_fwd_ok(int C, int dtype) {
@@ -224,13 +251,12 @@ extern "C" int mi355_gate_psi_fwd(const void* g1, int ldg, const void* x1, int l
   MI355_CHECK_ARG(g1 && x1 && scale_g && shift_g && scale_x && shift_x && w && z, "gate_psi_fwd: null pointer");
   MI355_CHECK_ARG(mi355_gate_psi_fwd_ok(C, dtype), "gate_psi_fwd: unsupported C=%d", C);
   const int epc = dtype_is_2byte(dtype) ? 8 : 4;
-  const int nb = rowreduce_blocks(M);
-  const int rpb = (int)((M + nb - 1) / nb);
+  const int nb = rowreduce_blocks(M);      // (the partial rows the one-channel BatchNorm folds: every workgroup writes its own)
   const int tpr = pow2_tpr(C / epc);
   return dispatch_dtype(dtype, "gate_psi_fwd", [&](auto tag) {
     using T = decltype(tag);
-    hipLaunchKernelGGL((gate_psi_fwd_kernel<T>), dim3(nb), dim3(256), 0, (hipStream_t)s, (const T*)g1, ldg, (const T*)x1, ldx, scale_g,
-                       shift_g, scale_x, shift_x, w, b, z, partial, M, C, rpb, tpr);
+    hipLaunchKernelGGL((gate_psi_fwd_kernel<T>), dim3(rowdot_grid(nb)), dim3(256), 0, (hipStream_t)s, (const T*)g1, ldg, (const T*)x1, ldx, scale_g,
+                       shift_g, scale_x, shift_x, w, b, z, partial, M, C, tpr, nb);
     MI355_LAUNCH_CHECK();
     return (int)MI355_OK;
   });
@@ -273,6 +299,7 @@ template <typename T> struct GateBnBwd {
 };
 
 template <typename T> struct GateBnBwdReduceOp : GateBnBwd<T> {
+  static constexpr int MAX_WGS = 512;         // ≈20 VALU instructions per element: two waves per SIMD (scripts/gate_bench.py: 256 / 512 / 768 = 3.9 / 4.8 / 4.6 TB/s)
   static constexpr int NQ = 5;
   static constexpr bool WRITES = false;
   typedef float Acc;
@@ -294,6 +321,7 @@ template <typename T> struct GateBnBwdReduceOp : GateBnBwd<T> {
 };
 
 template <typename T> struct GateBnBwdApplyOp : GateBnBwd<T> {
+  static constexpr int MAX_WGS = 512;         // (256 / 512 / 768 workgroups = 5.3 / 5.9 / 5.9 TB/s)
   static constexpr int NQ = 1;
   static constexpr bool WRITES = true;
   typedef float Acc;

@@ -255,7 +255,10 @@ int mi355_bn1_bwd_apply(const float* dzn, const float* z, const float* gamma, co
                         const float* invstd, const float* sums, float* dz, long long M, mi355_stream_t s);
 /* psi_in = relu(BN_g(g1) + BN_x(x1)) and z = psi conv of it in ONE pass over the raw branch outputs (instead of mi355_bn_act with a
  * second operand + mi355_rowdot_fwd): psi_in is computed as mi355_bn_act would have stored it and is not stored — the backward
- * below recomputes it as well.  partial: per-block (sum z, sum z^2) or null.  _ok: C / (16 / element size) <= 64. */
+ * below recomputes it as well.  partial: per-block (sum z, sum z^2) or null.  _ok: C / (16 / element size) <= 64.
+ * x1 == NULL (with scale_x / shift_x NULL): ONE normalised operand, z = w . relu(BN_g(g1)) + b — the logit head behind the last
+ * decoder layer (AttentionUNet.py:84,119); the two backward entry points accept the same (the x-branch arguments NULL, quantity 2
+ * of the partial rows zero, dx1 not written). */
 int mi355_gate_psi_fwd_ok(int C, int dtype);
 int mi355_gate_psi_fwd(const void* g1, int ldg, const void* x1, int ldx, const float* scale_g, const float* shift_g,
                        const float* scale_x, const float* shift_x, const float* w, const float* b, float* z,

@@ -176,7 +176,7 @@ extern "C" int mi355_rowdot_bwd(const float* dz, const void* x, int ldx, const f
 // z[m] = b + sum_c w[c] * psi_in[m][c] with psi_in computed from the raw branch outputs as mi355_bn_act would have stored it
 // (same fmaf chain, rounded to the storage type) — and NOT stored: the backward (mi355_gate_bn_bwd_*) recomputes it too.  The
 // dot product sums in mi355_rowdot_fwd's order.  Four rows per lane group are in flight (two 16-byte loads each).
-template <typename T>
+template <typename T, bool TWO>
 __global__ __launch_bounds__(256) void gate_psi_fwd_kernel(const T* __restrict__ g1, int ldg, const T* __restrict__ x1, int ldx,
                                                            const float* __restrict__ scale_g, const float* __restrict__ shift_g,
                                                            const float* __restrict__ scale_x, const float* __restrict__ shift_x,
@@ -199,8 +199,8 @@ __global__ __launch_bounds__(256) void gate_psi_fwd_kernel(const T* __restrict__
 #pragma unroll
   for (int e = 0; e < EPC; ++e) {
     sg[e] = scale_g[cb + e];
-    sx[e] = scale_x[cb + e];
-    sh[e] = shift_g[cb + e] + shift_x[cb + e];
+    sx[e] = TWO ? scale_x[cb + e] : 0.f;
+    sh[e] = TWO ? shift_g[cb + e] + shift_x[cb + e] : shift_g[cb + e];
     const float wv = w[cb + e];
     wr[e] = on ? wv : 0.f;
   }
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void gate_psi_fwd_kernel(const T* __restrict__
       const long long r = base + (long long)u * 4 * rpw + rsub;
       const size_t rc = (size_t)(r < r1 ? r : r1 - 1);
       gv[u] = ld16<T>(g1 + rc * ldg + cb);
-      xv[u] = ld16<T>(x1 + rc * ldx + cb);
+      if constexpr (TWO) xv[u] = ld16<T>(x1 + rc * ldx + cb);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -225,7 +225,8 @@ __global__ __launch_bounds__(256) void gate_psi_fwd_kernel(const T* __restrict__
       float acc = 0.f;      // (no guard: lanes past the last chunk carry zero weights, rows past the end are not stored)
 #pragma unroll
       for (int e = 0; e < EPC; ++e) {
-        const float f = __builtin_fmaf(to_f32<T>(xv[u].v[e]), sx[e], __builtin_fmaf(to_f32<T>(gv[u].v[e]), sg[e], sh[e]));
+        float f = __builtin_fmaf(to_f32<T>(gv[u].v[e]), sg[e], sh[e]);
+        if constexpr (TWO) f = __builtin_fmaf(to_f32<T>(xv[u].v[e]), sx[e], f);
         acc += to_f32<T>(from_f32<T>(fmaxf(f, 0.f))) * wr[e];
       }
       acc = seg_sum(acc, tpr);
@@ -248,15 +249,19 @@ extern "C" int mi355_gate_psi_fwd_ok(int C, int dtype) {
 extern "C" int mi355_gate_psi_fwd(const void* g1, int ldg, const void* x1, int ldx, const float* scale_g, const float* shift_g,
                                   const float* scale_x, const float* shift_x, const float* w, const float* b, float* z,
                                   float* partial, long long M, int C, int dtype, mi355_stream_t s) {
-  MI355_CHECK_ARG(g1 && x1 && scale_g && shift_g && scale_x && shift_x && w && z, "gate_psi_fwd: null pointer");
+  MI355_CHECK_ARG(g1 && scale_g && shift_g && w && z && (!x1 || (scale_x && shift_x)), "gate_psi_fwd: null pointer");
   MI355_CHECK_ARG(mi355_gate_psi_fwd_ok(C, dtype), "gate_psi_fwd: unsupported C=%d", C);
   const int epc = dtype_is_2byte(dtype) ? 8 : 4;
   const int nb = rowreduce_blocks(M);      // (the partial rows the one-channel BatchNorm folds: every workgroup writes its own)
   const int tpr = pow2_tpr(C / epc);
   return dispatch_dtype(dtype, "gate_psi_fwd", [&](auto tag) {
     using T = decltype(tag);
-    hipLaunchKernelGGL((gate_psi_fwd_kernel<T>), dim3(rowdot_grid(nb)), dim3(256), 0, (hipStream_t)s, (const T*)g1, ldg, (const T*)x1, ldx, scale_g,
-                       shift_g, scale_x, shift_x, w, b, z, partial, M, C, tpr, nb);
+    if (x1)
+      hipLaunchKernelGGL((gate_psi_fwd_kernel<T, true>), dim3(rowdot_grid(nb)), dim3(256), 0, (hipStream_t)s, (const T*)g1, ldg, (const T*)x1, ldx,
+                         scale_g, shift_g, scale_x, shift_x, w, b, z, partial, M, C, tpr, nb);
+    else      // one normalised operand: relu(bn(y)) in front of a one-channel convolution (the logit head, AttentionUNet.py:84)
+      hipLaunchKernelGGL((gate_psi_fwd_kernel<T, false>), dim3(rowdot_grid(nb)), dim3(256), 0, (hipStream_t)s, (const T*)g1, ldg, (const T*)nullptr, 0,
+                         scale_g, shift_g, nullptr, nullptr, w, b, z, partial, M, C, tpr, nb);
     MI355_LAUNCH_CHECK();
     return (int)MI355_OK;
   });
@@ -269,7 +274,7 @@ extern "C" int mi355_gate_psi_fwd(const void* g1, int ldg, const void* x1, int l
 // serve both branches at once: reduce reads g1, x1 and dz and leaves five quantities per channel,
 //   q0 = sum dp, q1 = sum dp * xhat_g, q2 = sum dp * xhat_x, q3 = sum dz * p (the psi weight's gradient), q4 = sum dz (its bias's);
 // apply reads the same and writes both branches' input gradients.
-template <typename T> struct GateBnBwd {
+template <typename T, bool TWO> struct GateBnBwd {
   static constexpr int EPC = 16 / (int)sizeof(T);
   const float* dz; const T* g1; int ldg; const T* x1; int ldx;
   const float* scale_g; const float* shift_g; const float* scale_x; const float* shift_x;
@@ -278,19 +283,29 @@ template <typename T> struct GateBnBwd {
   __device__ void load_common(int c0) {
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
-      sg[e] = scale_g[c0 + e]; sx[e] = scale_x[c0 + e]; sh[e] = shift_g[c0 + e] + shift_x[c0 + e];      // (BnActOp::load_cols)
-      mg[e] = mean_g[c0 + e]; ig[e] = invstd_g[c0 + e]; mx[e] = mean_x[c0 + e]; ix[e] = invstd_x[c0 + e];
+      sg[e] = scale_g[c0 + e]; mg[e] = mean_g[c0 + e]; ig[e] = invstd_g[c0 + e];
+      if constexpr (TWO) {
+        sx[e] = scale_x[c0 + e]; sh[e] = shift_g[c0 + e] + shift_x[c0 + e];      // (BnActOp::load_cols)
+        mx[e] = mean_x[c0 + e]; ix[e] = invstd_x[c0 + e];
+      } else {
+        sx[e] = 0.f; sh[e] = shift_g[c0 + e]; mx[e] = 0.f; ix[e] = 0.f;
+      }
       wr[e] = w[c0 + e];
     }
   }
   static constexpr int FETCH_ROWS = 4;
   struct In { Vec16<T> gv, xv; float d; };
   __device__ In fetch(size_t row, int c0) const {
-    return In{ld16_nt<T>(g1 + row * ldg + c0), ld16_nt<T>(x1 + row * ldx + c0), dz[row]};
+    In in;
+    in.gv = ld16_nt<T>(g1 + row * ldg + c0);
+    if constexpr (TWO) in.xv = ld16_nt<T>(x1 + row * ldx + c0);
+    in.d = dz[row];
+    return in;
   }
   // the activation as the forward stored it (BnActOp::finish with a second operand and ReLU)
   __device__ float act(const In& in, int e) const {
-    const float f = __builtin_fmaf(to_f32<T>(in.xv.v[e]), sx[e], __builtin_fmaf(to_f32<T>(in.gv.v[e]), sg[e], sh[e]));
+    float f = __builtin_fmaf(to_f32<T>(in.gv.v[e]), sg[e], sh[e]);
+    if constexpr (TWO) f = __builtin_fmaf(to_f32<T>(in.xv.v[e]), sx[e], f);
     return to_f32<T>(from_f32<T>(fmaxf(f, 0.f)));
   }
   // ... and its gradient as mi355_rowdot_bwd would have STORED it (rounded to the storage type): the two-pass backward is then
@@ -298,13 +313,13 @@ template <typename T> struct GateBnBwd {
   __device__ float dpsi(const In& in, int e, float p) const { return p > 0.f ? to_f32<T>(from_f32<T>(in.d * wr[e])) : 0.f; }
 };
 
-template <typename T> struct GateBnBwdReduceOp : GateBnBwd<T> {
+template <typename T, bool TWO> struct GateBnBwdReduceOp : GateBnBwd<T, TWO> {
   static constexpr int MAX_WGS = 512;         // ≈20 VALU instructions per element: two waves per SIMD (scripts/gate_bench.py: 256 / 512 / 768 = 3.9 / 4.8 / 4.6 TB/s)
   static constexpr int NQ = 5;
   static constexpr bool WRITES = false;
   typedef float Acc;
   static constexpr int EPC = 16 / (int)sizeof(T);
-  using typename GateBnBwd<T>::In;
+  using typename GateBnBwd<T, TWO>::In;
   __device__ void load_cols(int c0) { this->load_common(c0); }
   __device__ void finish(const In& in, size_t, int, Acc (&acc)[NQ][EPC]) const {
 #pragma unroll
@@ -313,20 +328,20 @@ template <typename T> struct GateBnBwdReduceOp : GateBnBwd<T> {
       const float dp = this->dpsi(in, e, p);
       acc[0][e] += dp;
       acc[1][e] += dp * (to_f32<T>(in.gv.v[e]) - this->mg[e]) * this->ig[e];
-      acc[2][e] += dp * (to_f32<T>(in.xv.v[e]) - this->mx[e]) * this->ix[e];
+      if constexpr (TWO) acc[2][e] += dp * (to_f32<T>(in.xv.v[e]) - this->mx[e]) * this->ix[e];
       acc[3][e] += in.d * p;
       acc[4][e] += in.d;
     }
   }
 };
 
-template <typename T> struct GateBnBwdApplyOp : GateBnBwd<T> {
+template <typename T, bool TWO> struct GateBnBwdApplyOp : GateBnBwd<T, TWO> {
   static constexpr int MAX_WGS = 512;         // (256 / 512 / 768 workgroups = 5.3 / 5.9 / 5.9 TB/s)
   static constexpr int NQ = 1;
   static constexpr bool WRITES = true;
   typedef float Acc;
   static constexpr int EPC = 16 / (int)sizeof(T);
-  using typename GateBnBwd<T>::In;
+  using typename GateBnBwd<T, TWO>::In;
   const float* gamma_g; const float* gamma_x; const float* sums_g; const float* sums_x;
   T* dg; int lddg; T* dx; int lddx; float invM; int C;
   float kg0[EPC], kg1[EPC], gg[EPC], kx0[EPC], kx1[EPC], gx[EPC];
@@ -335,7 +350,7 @@ template <typename T> struct GateBnBwdApplyOp : GateBnBwd<T> {
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
       gg[e] = gamma_g[c0 + e] * this->ig[e]; kg0[e] = sums_g[c0 + e] * invM; kg1[e] = sums_g[C + c0 + e] * invM;
-      gx[e] = gamma_x[c0 + e] * this->ix[e]; kx0[e] = sums_x[c0 + e] * invM; kx1[e] = sums_x[C + c0 + e] * invM;
+      if constexpr (TWO) { gx[e] = gamma_x[c0 + e] * this->ix[e]; kx0[e] = sums_x[c0 + e] * invM; kx1[e] = sums_x[C + c0 + e] * invM; }
     }
   }
   __device__ void finish(const In& in, size_t row, int c0, Acc (&)[NQ][EPC]) const {
@@ -344,16 +359,18 @@ template <typename T> struct GateBnBwdApplyOp : GateBnBwd<T> {
     for (int e = 0; e < EPC; ++e) {
       const float dp = this->dpsi(in, e, this->act(in, e));
       const float hg = (to_f32<T>(in.gv.v[e]) - this->mg[e]) * this->ig[e];
-      const float hx = (to_f32<T>(in.xv.v[e]) - this->mx[e]) * this->ix[e];
       og.v[e] = from_f32<T>(gg[e] * (dp - kg0[e] - hg * kg1[e]));
-      ox.v[e] = from_f32<T>(gx[e] * (dp - kx0[e] - hx * kx1[e]));
+      if constexpr (TWO) {
+        const float hx = (to_f32<T>(in.xv.v[e]) - this->mx[e]) * this->ix[e];
+        ox.v[e] = from_f32<T>(gx[e] * (dp - kx0[e] - hx * kx1[e]));
+      }
     }
     st16<T>(dg + row * lddg + c0, og);
-    st16<T>(dx + row * lddx + c0, ox);
+    if constexpr (TWO) st16<T>(dx + row * lddx + c0, ox);
   }
 };
 
-extern "C" int mi355_gate_bn_bwd_reduce_rows(long long M) { return rowred_grid<GateBnBwdReduceOp<bf16_t>>(M); }
+extern "C" int mi355_gate_bn_bwd_reduce_rows(long long M) { return rowred_grid<GateBnBwdReduceOp<bf16_t, true>>(M); }
 
 template <typename T, typename Op> static void fill_gate_bn(Op& op, const float* dz, const void* g1, int ldg, const void* x1, int ldx,
                                                             const float* const* co, const float* w) {
@@ -367,13 +384,18 @@ extern "C" int mi355_gate_bn_bwd_reduce(const float* dz, const void* g1, int ldg
                                         const float* shift_g, const float* mean_g, const float* invstd_g, const float* scale_x,
                                         const float* shift_x, const float* mean_x, const float* invstd_x, const float* w,
                                         float* partial, long long M, int C, int dtype, mi355_stream_t s) {
-  MI355_CHECK_ARG(dz && g1 && x1 && scale_g && shift_g && mean_g && invstd_g && scale_x && shift_x && mean_x && invstd_x && w && partial,
+  MI355_CHECK_ARG(dz && g1 && scale_g && shift_g && mean_g && invstd_g && w && partial && (!x1 || (scale_x && shift_x && mean_x && invstd_x)),
                   "gate_bn_bwd_reduce: null pointer");
   const float* co[8] = {scale_g, shift_g, mean_g, invstd_g, scale_x, shift_x, mean_x, invstd_x};
   return dispatch_dtype(dtype, "gate_bn_bwd_reduce", [&](auto tag) {
     using T = decltype(tag);
-    GateBnBwdReduceOp<T> op;
-    fill_gate_bn<T>(op, dz, g1, ldg, x1, ldx, co, w);
+    if (x1) {
+      GateBnBwdReduceOp<T, true> op;
+      fill_gate_bn<T>(op, dz, g1, ldg, x1, ldx, co, w);
+      return rowred_launch<T>(op, M, C, partial, (hipStream_t)s);
+    }
+    GateBnBwdReduceOp<T, false> op;        // one normalised operand (quantity 2 of the partial rows stays zero)
+    fill_gate_bn<T>(op, dz, g1, ldg, nullptr, 0, co, w);
     return rowred_launch<T>(op, M, C, partial, (hipStream_t)s);
   });
 }
@@ -383,16 +405,18 @@ extern "C" int mi355_gate_bn_bwd_apply(const float* dz, const void* g1, int ldg,
                                        const float* shift_x, const float* mean_x, const float* invstd_x, const float* w,
                                        const float* gamma_g, const float* gamma_x, const float* sums_g, const float* sums_x,
                                        void* dg1, int lddg, void* dx1, int lddx, long long M, int C, int dtype, mi355_stream_t s) {
-  MI355_CHECK_ARG(dz && g1 && x1 && scale_g && shift_g && mean_g && invstd_g && scale_x && shift_x && mean_x && invstd_x && w &&
-                  gamma_g && gamma_x && sums_g && sums_x && dg1 && dx1, "gate_bn_bwd_apply: null pointer");
+  MI355_CHECK_ARG(dz && g1 && scale_g && shift_g && mean_g && invstd_g && w && gamma_g && sums_g && dg1 &&
+                  (!x1 || (scale_x && shift_x && mean_x && invstd_x && gamma_x && sums_x && dx1)), "gate_bn_bwd_apply: null pointer");
   const float* co[8] = {scale_g, shift_g, mean_g, invstd_g, scale_x, shift_x, mean_x, invstd_x};
   return dispatch_dtype(dtype, "gate_bn_bwd_apply", [&](auto tag) {
     using T = decltype(tag);
-    GateBnBwdApplyOp<T> op;
-    fill_gate_bn<T>(op, dz, g1, ldg, x1, ldx, co, w);
-    op.gamma_g = gamma_g; op.gamma_x = gamma_x; op.sums_g = sums_g; op.sums_x = sums_x;
-    op.dg = (T*)dg1; op.lddg = lddg; op.dx = (T*)dx1; op.lddx = lddx; op.invM = (float)(1.0 / (double)M); op.C = C;
-    return rowred_launch<T>(op, M, C, nullptr, (hipStream_t)s);
+    auto run = [&](auto op) {
+      fill_gate_bn<T>(op, dz, g1, ldg, x1, ldx, co, w);
+      op.gamma_g = gamma_g; op.gamma_x = gamma_x; op.sums_g = sums_g; op.sums_x = sums_x;
+      op.dg = (T*)dg1; op.lddg = lddg; op.dx = (T*)dx1; op.lddx = lddx; op.invM = (float)(1.0 / (double)M); op.C = C;
+      return rowred_launch<T>(op, M, C, nullptr, (hipStream_t)s);
+    };
+    return x1 ? run(GateBnBwdApplyOp<T, true>{}) : run(GateBnBwdApplyOp<T, false>{});
   });
 }
 

@@ -29,12 +29,13 @@ CPAD = 32          # network inputs are zero-padded to 32 channels (MFMA K granu
 FUSE_POOL = os.environ.get("MI355_FUSE_POOL", "1") != "0"      # MaxPool2d(2, 2) inside the BatchNorm apply pass that feeds it (A/B switch)
 FUSE_POOL_BWD = os.environ.get("MI355_FUSE_POOL_BWD", "1") != "0"   # ... and its gradient inside that layer's two BatchNorm backward passes
 FUSE_GATE_BWD = os.environ.get("MI355_FUSE_GATE_BWD", "1") != "0"   # attention gate: both branches' BatchNorm backward in two passes, d(psi_in) never stored
+FUSE_HEAD = os.environ.get("MI355_FUSE_HEAD", "1") != "0"           # relu(bn(.)) in front of the one-channel logit convolution: never stored, both directions
 FUSE_RESIDUAL = os.environ.get("MI355_FUSE_RESIDUAL", "1") != "0"   # RRCNN_block's x0 + RCNN(x0) inside the last BatchNorm apply pass (A/B switch)
 
 
 class T:
     """NHWC activation handle: rows of C channels with channel stride ld inside `buf`."""
-    __slots__ = ("buf", "off", "N", "H", "W", "C", "ld", "_ng", "_grad", "parent", "_written", "name", "_plain_bn_relu", "_lazy_pool")
+    __slots__ = ("buf", "off", "N", "H", "W", "C", "ld", "_ng", "_grad", "parent", "_written", "name", "_plain_bn_relu", "_lazy_pool", "_bn_src", "_lazy_head")
 
     def __init__(self, buf, off, N, H, W, C, ld, parent=None):
         self.buf, self.off = buf, off
@@ -46,6 +47,8 @@ class T:
         self.name = ""
         self._plain_bn_relu = False     # relu(bn(conv(.))) with nothing added: produced by Builder.conv_bn_act in training
         self._lazy_pool = None          # gradient of a MaxPool2d(2, 2) of this tensor left to the producer's BatchNorm backward
+        self._bn_src = None             # (raw convolution output, BatchNorm coefficient buffers) this activation was computed from
+        self._lazy_head = None          # (dz, conv): the one-channel convolution whose backward the producer's BatchNorm passes compute
 
     @property
     def needs_grad(self):
@@ -633,12 +636,42 @@ class Builder:
                                    C, st["scale"], st["shift"]))
         return st
 
-    def _bn_bwd(self, da, a, y, bn, st, act, dres_to=None, bias=None, post_to=None, pool_dp=None):
+    def _bn_bwd(self, da, a, y, bn, st, act, dres_to=None, bias=None, post_to=None, pool_dp=None, head=None):
         """Emit BN(+ReLU) backward: returns dy (grad of the raw input y).  ``pool_dp``: the gradient of a MaxPool2d(2, 2) of the
         activation that maxpool() left for these passes to add on the fly (no mi355_maxpool_bwd pass over da)."""
         C = bn.num_features
         nb = lib.mi355_rowreduce_blocks(y.M)
         part = self.ws_f32(nb * 2 * C)
+        if head is not None:
+            # relu(bn(y)) feeds ONLY a one-channel 1x1 convolution (the logit head): its gradient dz[m] * w[c] * [a > 0] is recomputed
+            # from dz and y by the attention gate's two-pass kernels with ONE normalised operand; the same passes leave the head's
+            # weight / bias gradients (mi355_rowdot_bwd and the stored activation and its stored gradient all disappear)
+            dz, hconv = head
+            assert act and dres_to is None and post_to is None and pool_dp is None
+            part = self.ws_f32(nb * 5 * C)
+            co = (st["scale"], st["shift"], st["mean"], st["invstd"], None, None, None, None)
+            self.bwd.append(Launch("mi355_gate_bn_bwd_reduce", dz, y, y.ld, None, 0, *co, hconv.weight, part, y.M, C, self.code,
+                                   nbytes=y.M * C * self.esz + 4 * y.M))
+            if hconv.weight.requires_grad:
+                wref, wbeta = self.pgrad(hconv.weight)
+                self.bwd.append(Launch("mi355_colsum_finalize", self._ws_off(part, 3 * C * 4), nb, 5, C, wref, wbeta))
+                if hconv.bias is not None:
+                    bref2, bbeta = self.pgrad(hconv.bias)
+                    self.bwd.append(Launch("mi355_colsum_finalize", self._ws_off(part, 4 * C * 4), nb, 5 * C, 1, bref2, bbeta))
+            sums = self.f32(2 * C)
+            need_pg = bn.weight.requires_grad
+            if need_pg:
+                gref, gbeta = self.pgrad(bn.weight)
+                bref, _ = self.pgrad(bn.bias)
+            self.bwd.append(Launch("mi355_bn_bwd_finalize_at", part, min(nb, lib.mi355_gate_bn_bwd_reduce_rows(y.M)), 5, 0, 1, C, sums,
+                                   gref if need_pg else None, bref if need_pg else None, gbeta if need_pg else 0.0))
+            if bias is not None and bias.requires_grad and id(bias) not in self._grad_first:
+                self.pgrad(bias)
+                self.zero_grad_params.append(bias)
+            dy = self.grad_of(y)
+            self.bwd.append(Launch("mi355_gate_bn_bwd_apply", dz, y, y.ld, None, 0, *co, hconv.weight, bn.weight, None, sums, None,
+                                   dy, dy.ld, None, 0, y.M, C, self.code, nbytes=2 * y.M * C * self.esz + 4 * y.M))
+            return dy
         if pool_dp is not None:
             assert act and dres_to is None and post_to is None
             self.bwd.append(Launch("mi355_bn_bwd_reduce_pool2", da, da.ld, pool_dp, pool_dp.ld, y, y.ld, st["mean"], st["invstd"],
@@ -740,13 +773,17 @@ class Builder:
         if act:
             self.acts.append(("relu", a) if post_add is None else ("relu_pre", y, st["scale"], st["shift"]))
         a._plain_bn_relu = bool(act and r is None and self.training)      # (maxpool(): its gradient may ride in this layer's backward)
+        a._bn_src = (y, st)
 
         def rule():
             if not a.needs_grad:
                 return
-            da = self.grad_of(a)
-            # d(x + relu(.)) / dx = identity: folded into the BatchNorm apply pass
-            dy = self._bn_bwd(da, a, y, bn, st, act, dres_to=res, bias=conv.bias, post_to=post_add, pool_dp=getattr(a, "_lazy_pool", None))
+            if a._lazy_head is not None:      # logit_conv(): the gradient of `a` is dz[m] * w[c], recomputed inside the two passes
+                dy = self._bn_bwd(None, a, y, bn, st, act, bias=conv.bias, head=a._lazy_head)
+            else:
+                da = self.grad_of(a)
+                # d(x + relu(.)) / dx = identity: folded into the BatchNorm apply pass
+                dy = self._bn_bwd(da, a, y, bn, st, act, dres_to=res, bias=conv.bias, post_to=post_add, pool_dp=a._lazy_pool)
             conv_bwd(dy, bias_done=True)
         self.rule(rule)
         return a
@@ -1025,9 +1062,21 @@ class Builder:
         M, K, C, HW = x.M, conv.out_channels, x.C, x.H * x.W
         z = self.f32(M * K)
         self.see(conv.weight, conv.bias)
-        for k in range(K):
-            self.fwd.append(Launch("mi355_rowdot_fwd", x, x.ld, (conv.weight, k * C * 4), (conv.bias, k * 4) if conv.bias is not None else None,
-                                   (z, k * HW * 4), None, M, C, HW, K, self.code))
+        last = self.fwd[-1] if self.fwd else None
+        fused = (FUSE_HEAD and K == 1 and x._plain_bn_relu and x._bn_src is not None and last is not None and last.name == "mi355_bn_act"
+                 and last.args[10] is x and self.acts and self.acts[-1] == ("relu", x) and bool(lib.mi355_gate_psi_fwd_ok(C, self.code))
+                 and (x.needs_grad or not conv.weight.requires_grad))      # (the head's weight gradient comes out of the layer's backward passes)
+        if fused:
+            # x = relu(bn(y)) is read by this convolution only: one pass over y computes it on the fly (mi355_gate_psi_fwd with one
+            # normalised operand) — the activation is stored in neither direction (the backward recomputes it from y as well)
+            y, st = x._bn_src
+            self.fwd[-1] = Launch("mi355_gate_psi_fwd", y, y.ld, None, 0, st["scale"], st["shift"], None, None, conv.weight, conv.bias, z,
+                                  None, M, C, self.code, nbytes=M * C * self.esz + 4 * M)
+            self.acts[-1] = ("relu_pre", y, st["scale"], st["shift"])
+        else:
+            for k in range(K):
+                self.fwd.append(Launch("mi355_rowdot_fwd", x, x.ld, (conv.weight, k * C * 4), (conv.bias, k * 4) if conv.bias is not None else None,
+                                       (z, k * HW * 4), None, M, C, HW, K, self.code))
         self.output = ("z", z, (x.N, K, x.H, x.W))
         needs = x.needs_grad or conv.weight.requires_grad
         if self.want_grad and needs:
@@ -1035,6 +1084,9 @@ class Builder:
 
         def rule():
             if not needs:
+                return
+            if fused:
+                x._lazy_head = (self.dout, conv)      # conv_bn_act's rule (it runs next) emits the two passes
                 return
             nb = lib.mi355_rowreduce_blocks(M)
             dx = None

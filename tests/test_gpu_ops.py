@@ -344,6 +344,68 @@ def test_gate_branches_backward_in_two_passes(shape, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(2, 64, 16, 24), (3, 32, 5, 4)])
+def test_logit_head_behind_batchnorm_relu_in_one_pass_each_way(shape, dtype):
+    """The same kernels with ONE normalised operand (x1 = NULL): a = relu(BN(y)) in front of the one-channel logit convolution
+    (AttentionUNet.py:84) — forward z = w . a + b without storing a, backward of the BatchNorm and of the convolution's weight
+    and bias without storing a's gradient — against mi355_bn_act + mi355_rowdot_fwd / mi355_rowdot_bwd + mi355_bn_bwd_reduce /
+    _apply, and against torch autograd."""
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(c + w)
+    code = DTYPE_CODE[dtype]
+    m = n * h * w
+    y = q(torch.round(torch.randn(n, c, h, w, generator=g) * 4) / 4 + 0.125, dtype)
+    dz = torch.randn(m, generator=g)
+    wh = torch.randn(c, generator=g) * 0.5
+    gam = torch.rand(c, generator=g) + 0.5; bet = torch.randn(c, generator=g) * 0.3
+    mean = y.mean((0, 2, 3)); invstd = (y.var((0, 2, 3), unbiased=False) + 1e-5).rsqrt()
+    D = [dev(t.float().contiguous()) for t in (gam * invstd, bet - mean * gam * invstd, mean, invstd)]
+    yd, dzd, wd, gd, bh = to_nhwc(y, dtype), dev(dz), dev(wh), dev(gam), dev(torch.tensor([-0.21]))
+    nb = lib.mi355_rowreduce_blocks(m)
+    res = []
+    for fused in (0, 1):
+        dy = torch.zeros(n, h, w, c, dtype=dtype, device=DEV)
+        zz = torch.empty(m, device=DEV)
+        dw = torch.empty(c, device=DEV); db = torch.empty(1, device=DEV); sm = torch.empty(2 * c, device=DEV)
+        dga = torch.empty(c, device=DEV); dbe = torch.empty(c, device=DEV)
+        if fused:
+            lib.mi355_gate_psi_fwd(yd, c, None, 0, D[0], D[1], None, None, wd, bh, zz, None, m, c, code)
+            part = torch.full((nb * 5 * c,), float("nan"), device=DEV)
+            lib.mi355_gate_bn_bwd_reduce(dzd, yd, c, None, 0, D[0], D[1], D[2], D[3], None, None, None, None, wd, part, m, c, code)
+            lib.mi355_colsum_finalize(part.data_ptr() + 3 * c * 4, nb, 5, c, dw, 0.0)
+            lib.mi355_colsum_finalize(part.data_ptr() + 4 * c * 4, nb, 5 * c, 1, db, 0.0)
+            lib.mi355_bn_bwd_finalize_at(part, min(nb, lib.mi355_gate_bn_bwd_reduce_rows(m)), 5, 0, 1, c, sm, dga, dbe, 0.0)
+            lib.mi355_gate_bn_bwd_apply(dzd, yd, c, None, 0, D[0], D[1], D[2], D[3], None, None, None, None, wd, gd, None, sm, None,
+                                        dy, c, None, 0, m, c, code)
+        else:
+            a = torch.empty(n, h, w, c, dtype=dtype, device=DEV)
+            lib.mi355_bn_act(yd, c, D[0], D[1], None, 0, None, None, None, 0, a, c, m, c, 1, code)
+            lib.mi355_rowdot_fwd(a, c, wd, bh, zz, None, m, c, 0, 1, code)
+            da = torch.empty_like(a)
+            part = torch.full((nb * 2 * c,), float("nan"), device=DEV)
+            lib.mi355_rowdot_bwd(dzd, a, c, wd, da, c, part, m, c, 0, 0, 1, 0, code)
+            lib.mi355_colsum_finalize(part, nb, 2, c, dw, 0.0)
+            lib.mi355_colsum_finalize(part.data_ptr() + c * 4, nb, 2 * c, 1, db, 0.0)
+            part2 = torch.full((nb * 2 * c,), float("nan"), device=DEV)
+            lib.mi355_bn_bwd_reduce(da, c, None, 0, yd, c, D[2], D[3], D[0], D[1], part2, m, c, 1, code)
+            lib.mi355_bn_bwd_finalize(part2, min(nb, lib.mi355_bn_bwd_reduce_rows(m)), c, sm, dga, dbe, 0.0)
+            lib.mi355_bn_bwd_apply(da, c, None, 0, yd, c, gd, D[2], D[3], D[0], D[1], sm, dy, c, None, 0, None, 0, 0, None, m, c, 1, code)
+        torch.cuda.synchronize()
+        res.append([from_nhwc(dy.float().cpu()), dw.cpu(), db.cpu(), dga.cpu(), dbe.cpu(), zz.cpu()])
+    leaves = [t.clone().requires_grad_(True) for t in (y, wh, torch.zeros(1), gam, bet)]
+    pr = F.relu(F.batch_norm(leaves[0], None, None, leaves[3], leaves[4], True, 0.1, 1e-5))
+    z = (q(pr.detach(), dtype) + (pr - pr.detach())).permute(0, 2, 3, 1).reshape(m, c) @ leaves[1] + leaves[2]
+    (z * dz).sum().backward()
+    tol = TOL[dtype] if dtype != torch.float32 else 1e-4
+    assert rel_err(res[1][5], z.detach() - 0.21) < 2 * (TOL[dtype] if dtype != torch.float32 else 1e-5)
+    for i in range(5):
+        for r in res:
+            assert rel_err(r[i], leaves[i].grad) < 2 * tol, (i, rel_err(r[i], leaves[i].grad))
+        assert rel_err(res[1][i], res[0][i]) < (2e-5 if dtype == torch.float32 else tol), i
+    assert rel_err(res[1][5], res[0][5]) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_upsample_bwd_add_relu(dtype):
     n, c, h, w = 2, 32, 5, 7
     g = torch.Generator().manual_seed(9)

@@ -44,6 +44,10 @@ const char* mi355_last_error(void);
  * utils/helpers.py:318-322. */
 int mi355_pack_input_nchw(const float* x, void* y, int N, int C, int H, int W, int Cpad, int dtype,
                           mi355_stream_t s);
+/* The same input as the 3 x 3 patches of a stride-1, pad-1 convolution: y[n][h][w][c * 9 + kh * 3 + kw] = x[n][c][h + kh - 1][w + kw - 1]
+ * (zero outside the image), 32 channels per pixel, C <= 3.  The stem Conv2d(3, Co, 3, 1, 1) (AttentionUNet.py:6,60) is then a
+ * pointwise convolution over K = 27 -> 32 on the SAME parameter memory ([Co][3][3][3] read as [Co][27][1][1]). */
+int mi355_pack_input_im2col3(const float* x, void* y, int N, int C, int H, int W, int dtype, mi355_stream_t s);
 /* NHWC `dtype` (channel stride ld) -> NCHW fp32 (model outputs / logits). */
 int mi355_unpack_output_nchw(const void* x, float* y, int N, int C, int H, int W, int ld, int dtype,
                              mi355_stream_t s);

@@ -48,6 +48,45 @@ extern "C" int mi355_pack_input_nchw(const float* x, void* y, int N, int C, int 
   });
 }
 
+// The stem of the U-Nets / VGGs is Conv2d(3, Co, 3, 1, 1) on the network input (AttentionUNet.py:6,60; VGG.py): as a 32-channel
+// padded NHWC tensor it costs nine K steps of 29 zero channels each.  This pack writes the 3 x 3 patches instead — channel
+// k = c * 9 + kh * 3 + kw of pixel (h, w) is x[n][c][h + kh - 1][w + kw - 1] (zero outside the image, k >= 9 C: zero) — so the
+// stem is a POINTWISE convolution with K = 27 -> 32 on the same parameter memory ([Co][3][3][3] read as [Co][27]): the same bytes
+// written as the padded tensor, one ninth of the matrix work, and the streaming 1 x 1 kernels forward and for the weight gradient.
+template <typename T>
+__global__ void pack_im2col3_kernel(const float* __restrict__ x, T* __restrict__ y, int C, int H, int W, long long NHW, int ld) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  const int cp = 32 / EPC;
+  const long long HW = (long long)H * W, total = NHW * cp;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long pix = i % NHW;        // pixel fastest => plane reads are contiguous across lanes
+    const int ck = (int)(i / NHW);
+    const long long n = pix / HW, hw = pix - n * HW;
+    const int h = (int)(hw / W), w = (int)(hw - (long long)h * W);
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const int k = ck * EPC + e, c = k / 9, t = k - c * 9, hh = h + t / 3 - 1, ww = w + t % 3 - 1;
+      const bool in = c < C && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+      o.v[e] = from_f32<T>(in ? x[(n * C + c) * HW + (long long)hh * W + ww] : 0.f);
+    }
+    st16<T>(y + pix * ld + ck * EPC, o);
+  }
+}
+
+extern "C" int mi355_pack_input_im2col3(const float* x, void* y, int N, int C, int H, int W, int dtype, mi355_stream_t s) {
+  MI355_CHECK_ARG(x && y && C >= 1 && C <= 3 && N > 0, "pack_input_im2col3: bad arguments (C=%d: 9 C must fit 32 channels)", C);
+  const long long NHW = (long long)N * H * W;
+  return dispatch_dtype(dtype, "pack_input_im2col3", [&](auto tag) {
+    using T = decltype(tag);
+    long long blocks = (NHW * (32 / (16 / (int)sizeof(T))) + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL((pack_im2col3_kernel<T>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, x, (T*)y, C, H, W, NHW, 32);
+    MI355_LAUNCH_CHECK();
+    return (int)MI355_OK;
+  });
+}
+
 extern "C" int mi355_pack_nchw(const float* x, void* y, int N, int C, int H, int W, int ld, int dtype, mi355_stream_t s) {
   const int epc = dtype_is_2byte(dtype) ? 8 : 4;
   MI355_CHECK_ARG(x && y && C % epc == 0 && ld >= C, "pack_nchw: C=%d must be a multiple of %d", C, epc);

@@ -30,6 +30,7 @@ FUSE_POOL = os.environ.get("MI355_FUSE_POOL", "1") != "0"      # MaxPool2d(2, 2)
 FUSE_POOL_BWD = os.environ.get("MI355_FUSE_POOL_BWD", "1") != "0"   # ... and its gradient inside that layer's two BatchNorm backward passes
 FUSE_GATE_BWD = os.environ.get("MI355_FUSE_GATE_BWD", "1") != "0"   # attention gate: both branches' BatchNorm backward in two passes, d(psi_in) never stored
 FUSE_HEAD = os.environ.get("MI355_FUSE_HEAD", "1") != "0"           # relu(bn(.)) in front of the one-channel logit convolution: never stored, both directions
+STEM_IM2COL = os.environ.get("MI355_STEM_IM2COL", "1") != "0"       # Conv2d(3, Co, 3, 1, 1) on the network input as a pointwise convolution over its 3 x 3 patches
 FUSE_RESIDUAL = os.environ.get("MI355_FUSE_RESIDUAL", "1") != "0"   # RRCNN_block's x0 + RCNN(x0) inside the last BatchNorm apply pass (A/B switch)
 
 
@@ -299,6 +300,17 @@ class Plan:
         return any(p.data_ptr() != ptr for p, ptr in self.param_ptrs)
 
 
+class _StemAsPointwise:
+    """Conv2d(C <= 3, Co, 3, 1, 1) on the network input seen as Conv2d(9 C, Co, 1) on its im2col (mi355_pack_input_im2col3): the
+    SAME parameters — [Co][C][3][3] is [Co][9 C][1][1] in memory, so the weight packs and the weight gradient land where they belong."""
+
+    def __init__(self, conv):
+        self.weight, self.bias = conv.weight, conv.bias
+        self.in_channels, self.out_channels = conv.in_channels * 9, conv.out_channels
+        self.kernel_size, self.stride, self.padding, self.dilation, self.groups = (1, 1), (1, 1), (0, 0), (1, 1), 1
+        self.pack_shape = (conv.out_channels, conv.in_channels * 9, 1)
+
+
 class Builder:
     """Emits forward launches and registers reverse-mode rules; `finish()` returns a Plan."""
     fuse_residual = FUSE_RESIDUAL
@@ -420,7 +432,22 @@ class Builder:
         xin = self.new_tensor(N, H, W, cpad)
         self.pre.append(Launch("mi355_pack_input_nchw", self.input[0], xin, N, C, H, W, cpad, self.code))
         self.input_grad = None
+        self._xin, self._xin_pack, self._xin_users, self._xcol, self._stem = xin, self.pre[-1], 0, None, {}
         return xin
+
+    def _stem_as_pointwise(self, x, conv, up):
+        """(im2col tensor, pointwise view of conv) when conv is the 3 x 3 stem on the network input, else None."""
+        if not (STEM_IM2COL and x is getattr(self, "_xin", None) and self.esz == 2 and not up and not x.needs_grad
+                and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1)
+                and conv.in_channels == self.input[1][1] and conv.in_channels * 9 <= CPAD and conv.groups == 1):
+            return None
+        if self._xcol is None:
+            N, C, H, W = self.input[1]
+            self._xcol = self.new_tensor(N, H, W, CPAD)
+            self.pre.append(Launch("mi355_pack_input_im2col3", self.input[0], self._xcol, N, C, H, W, self.code))
+        if id(conv) not in self._stem:
+            self._stem[id(conv)] = _StemAsPointwise(conv)
+        return self._xcol, self._stem[id(conv)]
 
     def want_input_grad(self, xin):
         """Make the packed network input differentiable (block-level tests / composed pipelines): after
@@ -470,6 +497,8 @@ class Builder:
             else:
                 co, ci = w.shape[0], w.shape[1]
             k = w.shape[2]
+            if hasattr(conv, "pack_shape"):
+                co, ci, k = conv.pack_shape
             wf = self._alloc(co * k * k * cip)
             wb = self._alloc(co * k * k * cip) if self.want_grad else None
             assert k * k <= 288, "batched weight pack: at most 288 taps"
@@ -491,6 +520,11 @@ class Builder:
         ``stats`` the BatchNorm partial sums of y are produced by the conv epilogue when the kernel supports
         it (``self._last_stat_rows`` > 0 afterwards).  ``relu``: max(0, .) in the epilogue.  ``fold = (scale, bias)``:
         eval-mode BatchNorm folded into the packed weights and the bias (forward-only plans)."""
+        stem = self._stem_as_pointwise(x, conv, up)
+        if stem is not None:
+            return self.conv_raw(stem[0], stem[1], out=out, stats=stats, relu=relu, fold=fold)
+        if x is getattr(self, "_xin", None):
+            self._xin_users += 1
         k, s, p, Ho, Wo = self._conv_geom(x, conv, up)
         Co = conv.out_channels
         assert x.C >= conv.in_channels and (x.C == conv.in_channels or conv.in_channels < CPAD), (x.C, conv.in_channels)
@@ -1268,6 +1302,13 @@ class Builder:
 
     # ---- finish -------------------------------------------------------------------------------------------------------------
     def finish(self):
+        if getattr(self, "_xcol", None) is not None:
+            # the stem reads the im2col of the input: that pack takes the place of the plain one as launch 0 (the launch whose source
+            # pointer Plan.run_forward patches to the caller's tensor)
+            if self._xin_users:
+                raise NotImplementedError("network input read both by a 3x3 stem (as im2col) and by another layer")
+            col = [l for l in self.pre if l.name == "mi355_pack_input_im2col3"]
+            self.pre = col + [l for l in self.pre if l is not self._xin_pack and l.name != "mi355_pack_input_im2col3"]
         if self._pack_table:
             rows = [[w.data_ptr(), wf.data_ptr(), wb.data_ptr() if wb is not None else 0, co, ci, cip, taps, tr,
                      sc.data_ptr() if sc is not None else 0] for (w, wf, wb, co, ci, cip, taps, tr, sc) in self._pack_table]

@@ -405,6 +405,34 @@ def test_logit_head_behind_batchnorm_relu_in_one_pass_each_way(shape, dtype):
     assert rel_err(res[1][5], res[0][5]) < 1e-6
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("shape", [(2, 3, 9, 7), (1, 1, 4, 16), (3, 2, 16, 8)])
+def test_input_im2col_and_the_stem_as_a_pointwise_convolution(shape, dtype):
+    """mi355_pack_input_im2col3 against F.unfold (channel c * 9 + kh * 3 + kw, zero outside the image, zero beyond 9 C), and the
+    stem Conv2d(C, Co, 3, 1, 1) computed as the pointwise convolution of that tensor with the SAME weight memory
+    ([Co][C][3][3] read as [Co][9 C][1][1]) against F.conv2d (AttentionUNet.py:6,60)."""
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(h * w)
+    x = torch.randn(n, c, h, w, generator=g)
+    code = DTYPE_CODE[dtype]
+    y = torch.full((n, h, w, 32), float("nan"), dtype=dtype, device=DEV)
+    lib.mi355_pack_input_im2col3(dev(x), y, n, c, h, w, code)
+    torch.cuda.synchronize()
+    ref = F.unfold(x, 3, padding=1).view(n, c * 9, h, w)                      # channel order (c, kh, kw)
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    assert torch.equal(got[:, :c * 9], q(ref, dtype)) and float(got[:, c * 9:].abs().sum()) == 0
+    if dtype == torch.float32:
+        return
+    co = 64
+    wt = torch.randn(co, c, 3, 3, generator=g) / (c * 9) ** 0.5
+    b = torch.randn(co, generator=g)
+    wf, _ = pack_w(wt.view(co, c * 9, 1, 1), dtype, cip=32)
+    out = torch.empty(n, h, w, co, dtype=dtype, device=DEV)
+    lib.mi355_conv2d_igemm(y, wf, dev(b), out, n, h, w, 32, 32, h, w, co, co, 1, 1, 1, 1, 0, 1, 0, 0, None, code)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(out), F.conv2d(q(x, dtype), q(wt, dtype), b, padding=1)) < TOL[dtype]
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_upsample_bwd_add_relu(dtype):
     n, c, h, w = 2, 32, 5, 7

@@ -150,6 +150,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(const ConvArgs a, co
     for (int i = 0; i < WS64_SKEW; ++i) __builtin_amdgcn_s_sleep(32);
   }
 #endif
+  // fused BatchNorm statistics: per-lane running sums over ALL tiles of the workgroup (one channel tile, so a lane always meets the
+  // same four channels) — ONE partial row per workgroup behind the loop (row kk: mi355_conv2d_igemm_stat_rows == groups), not one
+  // per tile: 512 rows instead of 8192 at 256 x 256 x 32 images (no pre-fold launch, a 16 x smaller fold)
+  f32x2 wsm[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}}, wsq[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
   for (int sp = sp_begin; sp < sp_end; ++sp) {
     int t = sp;
     const int tx = t % TXN; t /= TXN;
@@ -260,9 +264,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(const ConvArgs a, co
     struct alignas(8) Pack4 { T v[4]; };
     auto finish = [&](auto relu_tag, auto stats_tag) __attribute__((always_inline)) {
       constexpr bool RELU = decltype(relu_tag)::value, STATS = decltype(stats_tag)::value;
-      f32x2 sm[2], sq[2];
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) { sm[jj] = f32x2{0.f, 0.f}; sq[jj] = f32x2{0.f, 0.f}; }
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
         const int row = mb * 16 + l16;                                   // tile pixel: block mb = (output row, xb)
@@ -273,22 +274,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(const ConvArgs a, co
 #pragma unroll
           for (int jj = 0; jj < 2; ++jj) {
             const f32x2 v = {to_f32<T>(pk.v[2 * jj]), to_f32<T>(pk.v[2 * jj + 1])};
-            sm[jj] += v;
-            sq[jj] += v * v;
+            wsm[jj] += v;
+            wsq[jj] += v * v;
           }
         }
         *reinterpret_cast<Pack4*>(cst + row * C_PITCH + (wave * 16 + 4 * c4) * 2) = pk;
-      }
-      if constexpr (STATS) {                                             // a wave has seen all 256 pixels of its 16 channels: no exchange
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float s1 = row16_sum(sm[r >> 1][r & 1]), s2 = row16_sum(sq[r >> 1][r & 1]);
-          if (l16 == 0) {
-            float* st = a.stats + (size_t)sp * 2 * a.Co + n0 + wave * 16 + 4 * c4 + r;
-            st[0] = s1;
-            st[a.Co] = s2;
-          }
-        }
       }
     };
     using Yes = std::true_type;
@@ -357,6 +347,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(const ConvArgs a, co
 #pragma unroll
     for (int it = 0; it < NSTORE; ++it) store_pending(it);
   }
+  if (a.stats) {                                                         // a wave has seen every pixel of its 16 channels: no exchange between waves
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float s1 = row16_sum(wsm[r >> 1][r & 1]), s2 = row16_sum(wsq[r >> 1][r & 1]);
+      if (l16 == 0) {
+        float* st = a.stats + (size_t)kk * 2 * a.Co + n0 + wave * 16 + 4 * c4 + r;
+        st[0] = s1;
+        st[a.Co] = s2;
+      }
+    }
+  }
 }
 
 // 2 workgroups per CU, each a contiguous range of spatial tiles of one channel tile
@@ -367,12 +368,20 @@ static int ws_tile_rows(int Ci, int Ho, int Wo, int Co) {               // 8 / 4
   return 0;
 }
 
+// spatial groups of a launch (= its statistics rows): a multiple of 8 (one share per XCD), every group gets at least one tile
+static int ws_groups(int N, int Ho, int Wo, int Co, int th, int cus) {
+  const int NT = Co / 64;
+  const int S = N * (Ho / th) * (Wo / 32);
+  int groups = (2 * cus / NT) & ~7;
+  if (groups > (S & ~7)) groups = S & ~7;
+  return groups;
+}
+
 template <typename T, int CI, int TH>
 static int launch_ws(const ConvArgs& a, hipStream_t s, int cus) {
   const int NT = a.Co / 64;
   const int S = a.N * (a.Ho / TH) * (a.Wo / 32);
-  int groups = (2 * cus / NT) & ~7;                                      // spatial groups: a multiple of 8 (one share per XCD)
-  if (groups > (S & ~7)) groups = S & ~7;
+  const int groups = ws_groups(a.N, a.Ho, a.Wo, a.Co, TH, cus);
   if (groups < 8) MI355_FAIL(MI355_ERR_ARG, "conv3x3_ws: %d spatial tiles are too few for the persistent kernel", S);
   constexpr int lds_bytes = WsCfg<CI, TH>::LDS_BYTES;
   static const hipError_t configured = hipFuncSetAttribute((const void*)conv3x3_ws_kernel<T, CI, TH>,

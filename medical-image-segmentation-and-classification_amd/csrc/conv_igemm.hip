@@ -624,8 +624,8 @@ extern "C" int mi355_conv2d_igemm_stat_rows(int N, int Hi, int Wi, int Ci, int H
   switch (final_variant(N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up, dtype)) {
     case IG_HALO_PP:
     case IG_HALO_PP128: return N * (Ho / 16) * (Wo / 32);
-    case IG_WS128: return N * (Ho / 4) * (Wo / 32);
-    case IG_WS64:
+    case IG_WS128: return ws_groups(N, Ho, Wo, Co, 4, device_cus());      // persistent kernels: one row per workgroup range
+    case IG_WS64: return ws_groups(N, Ho, Wo, Co, 8, device_cus());
     case IG_HALO_8x32: return N * (Ho / 8) * (Wo / 32);
     case IG_HALO_16x16: return N * (Ho / 16) * (Wo / 16);
     case IG_DMA: return ceil_div((long long)N * Ho * Wo, 128);

@@ -410,11 +410,12 @@ def test_weight_stationary_variant_dispatch():
     assert lib.mi355_conv2d_igemm_variant_n(2, 64, 64, 128, 64, 64, 128, 3, 3, 1, 1, -1, 1, 0, code) == 2          # 128 tiles: too few
     assert lib.mi355_conv2d_igemm_variant_n(16, 128, 128, 128, 128, 128, 128, 3, 3, 1, 1, -1, 1, 0, code) == 2     # 8 tiles per workgroup: the 4-wave kernel
     assert lib.mi355_conv2d_igemm_variant_n(32, 64, 64, 128, 64, 64, 256, 3, 3, 1, 1, -1, 1, 0, code) == 2
-    assert lib.mi355_conv2d_igemm_stat_rows(32, 128, 128, 128, 128, 128, 128, 3, 3, 1, 1, -1, 1, 0, code) == 32 * 32 * 4
+    # the persistent kernel leaves ONE statistics row per workgroup range (2 per CU, shared by the channel tiles), not one per tile
+    assert lib.mi355_conv2d_igemm_stat_rows(32, 128, 128, 128, 128, 128, 128, 3, 3, 1, 1, -1, 1, 0, code) == 256        # of 4096 tiles
     assert lib.mi355_conv2d_igemm_variant(16, 16, 64, 16, 16, 64, 3, 3, 1, 1, -1, 1, 0, code) == 3
     assert lib.mi355_conv2d_igemm_variant_n(32, 256, 256, 64, 256, 256, 64, 3, 3, 1, 1, -1, 1, 0, code) == 7
     assert lib.mi355_conv2d_igemm_variant_n(2, 64, 64, 64, 64, 64, 64, 3, 3, 1, 1, -1, 1, 0, code) == 2           # 32 tiles: too few
-    assert lib.mi355_conv2d_igemm_stat_rows(32, 256, 256, 64, 256, 256, 64, 3, 3, 1, 1, -1, 1, 0, code) == 32 * 32 * 8
+    assert lib.mi355_conv2d_igemm_stat_rows(32, 256, 256, 64, 256, 256, 64, 3, 3, 1, 1, -1, 1, 0, code) == 512           # of 8192 tiles
     assert lib.mi355_conv2d_igemm_variant_n(2, 64, 64, 64, 64, 64, 64, 3, 3, 1, 1, -1, 1, 0, DTYPE_CODE[torch.float32]) == 0
 
 

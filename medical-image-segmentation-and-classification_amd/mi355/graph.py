@@ -31,6 +31,7 @@ FUSE_POOL_BWD = os.environ.get("MI355_FUSE_POOL_BWD", "1") != "0"   # ... and it
 FUSE_GATE_BWD = os.environ.get("MI355_FUSE_GATE_BWD", "1") != "0"   # attention gate: both branches' BatchNorm backward in two passes, d(psi_in) never stored
 FUSE_HEAD = os.environ.get("MI355_FUSE_HEAD", "1") != "0"           # relu(bn(.)) in front of the one-channel logit convolution: never stored, both directions
 STEM_IM2COL = os.environ.get("MI355_STEM_IM2COL", "1") != "0"       # Conv2d(3, Co, 3, 1, 1) on the network input as a pointwise convolution over its 3 x 3 patches
+SIDE_COLSUM = os.environ.get("MI355_SIDE_COLSUM", "1") != "0"       # psi / head weight-gradient folds (they only feed the optimiser) leave the main stream
 FUSE_RESIDUAL = os.environ.get("MI355_FUSE_RESIDUAL", "1") != "0"   # RRCNN_block's x0 + RCNN(x0) inside the last BatchNorm apply pass (A/B switch)
 
 
@@ -682,16 +683,17 @@ class Builder:
             # weight / bias gradients (mi355_rowdot_bwd and the stored activation and its stored gradient all disappear)
             dz, hconv = head
             assert act and dres_to is None and post_to is None and pool_dp is None
-            part = self.ws_f32(nb * 5 * C)
+            part = self.f32(nb * 5 * C) if SIDE_COLSUM else self.ws_f32(nb * 5 * C)      # (its own buffer: read from the side stream)
             co = (st["scale"], st["shift"], st["mean"], st["invstd"], None, None, None, None)
             self.bwd.append(Launch("mi355_gate_bn_bwd_reduce", dz, y, y.ld, None, 0, *co, hconv.weight, part, y.M, C, self.code,
                                    nbytes=y.M * C * self.esz + 4 * y.M))
+            head_folds = []
             if hconv.weight.requires_grad:
                 wref, wbeta = self.pgrad(hconv.weight)
-                self.bwd.append(Launch("mi355_colsum_finalize", self._ws_off(part, 3 * C * 4), nb, 5, C, wref, wbeta))
+                head_folds.append(Launch("mi355_colsum_finalize", self._ws_off(part, 3 * C * 4), nb, 5, C, wref, wbeta, side=SIDE_COLSUM))
                 if hconv.bias is not None:
                     bref2, bbeta = self.pgrad(hconv.bias)
-                    self.bwd.append(Launch("mi355_colsum_finalize", self._ws_off(part, 4 * C * 4), nb, 5 * C, 1, bref2, bbeta))
+                    head_folds.append(Launch("mi355_colsum_finalize", self._ws_off(part, 4 * C * 4), nb, 5 * C, 1, bref2, bbeta, side=SIDE_COLSUM))
             sums = self.f32(2 * C)
             need_pg = bn.weight.requires_grad
             if need_pg:
@@ -705,6 +707,7 @@ class Builder:
             dy = self.grad_of(y)
             self.bwd.append(Launch("mi355_gate_bn_bwd_apply", dz, y, y.ld, None, 0, *co, hconv.weight, bn.weight, None, sums, None,
                                    dy, dy.ld, None, 0, y.M, C, self.code, nbytes=2 * y.M * C * self.esz + 4 * y.M))
+            self.bwd += head_folds        # (they only feed the optimiser: behind the apply pass, off the main stream)
             return dy
         if pool_dp is not None:
             assert act and dres_to is None and post_to is None
@@ -777,7 +780,8 @@ class Builder:
             self.ws, self.off = ws, off
 
     def _ws_off(self, ws, off):
-        return Builder._WsOff(ws, off)
+        """`off` bytes into a shared workspace (bound when the plan is finished) or into a buffer of its own."""
+        return Builder._WsOff(ws, off) if isinstance(ws, Ws) else (ws, off)
 
     # ---- fused block ops -------------------------------------------------------------------------------------
     def conv_bn_act(self, x, conv, bn, act=True, up=False, out=None, res=None, post_add=None):
@@ -1047,12 +1051,11 @@ class Builder:
             if fused:
                 # psi conv (F_int -> 1) and the two normalised branches in two passes: dp = dz * w masked by p > 0 is recomputed from
                 # the raw branch outputs where it is needed (mi355_rowdot_bwd would write it, four BatchNorm passes read it)
-                part3 = self.ws_f32(nb * 5 * F_int)
+                # (a buffer of its own, not the shared workspace: the side stream reads it while the main stream moves on)
+                part3 = self.f32(nb * 5 * F_int) if SIDE_COLSUM else self.ws_f32(nb * 5 * F_int)
                 co = (sg["scale"], sg["shift"], sg["mean"], sg["invstd"], sx["scale"], sx["shift"], sx["mean"], sx["invstd"])
                 self.bwd.append(Launch("mi355_gate_bn_bwd_reduce", dz, g1, g1.ld, x1, x1.ld, *co, cp.weight, part3, M, F_int, self.code,
                                        nbytes=2 * M * F_int * self.esz + 4 * M))
-                self.bwd.append(Launch("mi355_colsum_finalize", self._ws_off(part3, 3 * F_int * 4), nb, 5, F_int, wref, wbeta))
-                self.bwd.append(Launch("mi355_colsum_finalize", self._ws_off(part3, 4 * F_int * 4), nb, 5 * F_int, 1, bref2, bbeta))
                 nbf = min(nb, lib.mi355_gate_bn_bwd_reduce_rows(M))
                 sums = []
                 for q1, bn_, bias_ in ((1, bg, cg.bias), (2, bx, cx.bias)):
@@ -1071,6 +1074,9 @@ class Builder:
                 self.bwd.append(Launch("mi355_gate_bn_bwd_apply", dz, g1, g1.ld, x1, x1.ld, *co, cp.weight, bg.weight, bx.weight,
                                        sums[0], sums[1], dg1, dg1.ld, dx1, dx1.ld, M, F_int, self.code,
                                        nbytes=4 * M * F_int * self.esz + 4 * M))
+                # (the psi convolution's own gradients only feed the optimiser: folded behind the apply pass, off the main stream)
+                self.bwd.append(Launch("mi355_colsum_finalize", self._ws_off(part3, 3 * F_int * 4), nb, 5, F_int, wref, wbeta, side=SIDE_COLSUM))
+                self.bwd.append(Launch("mi355_colsum_finalize", self._ws_off(part3, 4 * F_int * 4), nb, 5 * F_int, 1, bref2, bbeta, side=SIDE_COLSUM))
                 g1_bwd(dg1, bias_done=True)
                 x1_bwd(dx1, bias_done=True)
                 return

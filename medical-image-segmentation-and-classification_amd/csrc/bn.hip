@@ -294,16 +294,18 @@ __global__ __launch_bounds__(256) void bn_act_pool2_kernel(const T* __restrict__
       }
       st16<T>(y + (r0 + (size_t)(k >> 1) * W + (k & 1)) * ldy + c0, o);
     }
-    Vec16<T> o;
+    if (p) {
+      Vec16<T> o;
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) o.v[e] = from_f32<T>(m[e]);
-    st16<T>(p + ((size_t)(n * Ho + ho) * Wo + wo) * ldp + c0, o);
+      for (int e = 0; e < EPC; ++e) o.v[e] = from_f32<T>(m[e]);
+      st16<T>(p + ((size_t)(n * Ho + ho) * Wo + wo) * ldp + c0, o);
+    }
   }
 }
 
 extern "C" int mi355_bn_act_pool2(const void* x, int ldx, const float* scale, const float* shift, void* y, int ldy, void* p, int ldp,
                                   int N, int H, int W, int C, int act, int dtype, mi355_stream_t s) {
-  MI355_CHECK_ARG(x && scale && shift && y && p && N > 0, "bn_act_pool2: bad arguments");
+  MI355_CHECK_ARG(x && scale && shift && y && N > 0, "bn_act_pool2: bad arguments");
   MI355_CHECK_ARG(H % 2 == 0 && W % 2 == 0, "bn_act_pool2: %d x %d is not divisible into 2 x 2 groups", H, W);
   const int epc = dtype_is_2byte(dtype) ? 8 : 4;
   MI355_CHECK_ARG(C % epc == 0, "bn_act_pool2: C=%d must be a multiple of %d", C, epc);

@@ -32,6 +32,7 @@ FUSE_GATE_BWD = os.environ.get("MI355_FUSE_GATE_BWD", "1") != "0"   # attention 
 FUSE_HEAD = os.environ.get("MI355_FUSE_HEAD", "1") != "0"           # relu(bn(.)) in front of the one-channel logit convolution: never stored, both directions
 STEM_IM2COL = os.environ.get("MI355_STEM_IM2COL", "1") != "0"       # Conv2d(3, Co, 3, 1, 1) on the network input as a pointwise convolution over its 3 x 3 patches
 SIDE_COLSUM = os.environ.get("MI355_SIDE_COLSUM", "1") != "0"       # psi / head weight-gradient folds (they only feed the optimiser) leave the main stream
+BN_ACT_WINDOWS = os.environ.get("MI355_BN_ACT_WINDOWS", "1") != "0"  # plain BatchNorm apply passes on even images run the window-ordered kernel (mi355_bn_act_pool2 without a pooled output)
 FUSE_RESIDUAL = os.environ.get("MI355_FUSE_RESIDUAL", "1") != "0"   # RRCNN_block's x0 + RCNN(x0) inside the last BatchNorm apply pass (A/B switch)
 
 
@@ -1308,6 +1309,16 @@ class Builder:
 
     # ---- finish -------------------------------------------------------------------------------------------------------------
     def finish(self):
+        if BN_ACT_WINDOWS:
+            # plain BatchNorm apply passes on even images (no second operand, no residual, not absorbed by a pooling / gate / head
+            # peephole meanwhile): the window-ordered kernel without a pooled output — the same values, ≈8 % faster
+            for i, l in enumerate(self.fwd):
+                a_ = l.args
+                if l.name == "mi355_bn_act" and a_[4] is None and a_[8] is None and isinstance(a_[10], T) and a_[10].H % 2 == 0 \
+                        and a_[10].W % 2 == 0 and a_[12] == a_[10].M:
+                    t = a_[10]
+                    self.fwd[i] = Launch("mi355_bn_act_pool2", a_[0], a_[1], a_[2], a_[3], t, t.ld, None, 0, t.N, t.H, t.W, t.C, a_[14],
+                                         self.code, nbytes=l.bytes)
         if getattr(self, "_xcol", None) is not None:
             # the stem reads the im2col of the input: that pack takes the place of the plain one as launch 0 (the launch whose source
             # pointer Plan.run_forward patches to the caller's tensor)

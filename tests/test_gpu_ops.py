@@ -174,6 +174,11 @@ def test_bn_act_with_fused_maxpool_is_bit_identical_to_the_two_passes(dtype, act
     assert rel_err(from_nhwc(outs[1][0][..., 8:]), ref) < TOL[dtype]
     assert rel_err(from_nhwc(outs[1][1][..., 16:]), F.max_pool2d(q(ref, dtype), 2, 2)) < TOL[dtype]
     assert float(outs[1][0][..., :8].abs().sum()) == 0 and float(outs[1][1][..., :16].abs().sum()) == 0
+    # without a pooled output (p = NULL): the activation alone, the same bits
+    y = torch.zeros(n, h, w, c + 8, dtype=dtype, device=DEV)
+    lib.mi355_bn_act_pool2(xd, c, dev(sc), dev(sh), y.data_ptr() + 8 * es, c + 8, None, 0, n, h, w, c, act, code)
+    torch.cuda.synchronize()
+    assert torch.equal(y.cpu(), outs[0][0])
 
 
 @pytest.mark.parametrize("dtype", DT)

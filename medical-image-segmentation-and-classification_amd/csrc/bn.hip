@@ -201,7 +201,7 @@ template <typename T> struct BnActOp {
   const T* x2; int ldx2; const float* scale2; const float* shift2;
   const T* res; int ldr;
   T* y; int ldy;
-  int act;
+  int act; int keep;
   float sc[EPC], sh[EPC], sc2[EPC];
   __device__ void load_cols(int c0) {
 #pragma unroll
@@ -216,7 +216,7 @@ template <typename T> struct BnActOp {
   struct In { Vec16<T> v, v2, vr; };
   __device__ In fetch(size_t row, int c0) const {
     In in;
-    in.v = ld16_nt<T>(x + row * ldx + c0);         // (the raw conv output is not read again before the backward pass: nontemporal)
+    in.v = keep ? ld16<T>(x + row * ldx + c0) : ld16_nt<T>(x + row * ldx + c0);      // (the raw conv output is not read again before the backward pass: nontemporal)
     if (x2) in.v2 = ld16<T>(x2 + row * ldx2 + c0);
     if (res) in.vr = ld16<T>(res + row * ldr + c0);
     return in;
@@ -252,7 +252,8 @@ extern "C" int mi355_bn_act(const void* x, int ldx, const float* scale, const fl
   MI355_CHECK_ARG(!x2 || (scale2 && shift2), "bn_act: second operand needs scale2/shift2");
   return dispatch_dtype(dtype, "bn_act", [&](auto tag) {
     using T = decltype(tag);
-    BnActOp<T> op{(const T*)x, ldx, scale, shift, (const T*)x2, ldx2, scale2, shift2, (const T*)res, ldr, (T*)y, ldy, act};
+    const int act_keep = 0;      // (streaming read of the raw convolution output: the default policy measured +0.09 ms per step)
+    BnActOp<T> op{(const T*)x, ldx, scale, shift, (const T*)x2, ldx2, scale2, shift2, (const T*)res, ldr, (T*)y, ldy, act, act_keep};
     return rowmap_launch<T>(op, M, C, (hipStream_t)s);
   });
 }
@@ -264,7 +265,7 @@ extern "C" int mi355_bn_act(const void* x, int ldx, const float* scale, const fl
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_pool2_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, T* __restrict__ y, int ldy,
-                                                           T* __restrict__ p, int ldp, int N, int H, int W, int C, int act) {
+                                                           T* __restrict__ p, int ldp, int N, int H, int W, int C, int act, int keep) {
   constexpr int EPC = 16 / (int)sizeof(T);
   const int cp = C / EPC, Ho = H >> 1, Wo = W >> 1;
   const long long total = (long long)N * Ho * Wo * cp;
@@ -280,7 +281,8 @@ __global__ __launch_bounds__(256) void bn_act_pool2_kernel(const T* __restrict__
     const size_t r0 = ((size_t)(n * H + 2 * ho) * W + 2 * wo);
     Vec16<T> in[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) in[k] = ld16_nt<T>(x + (r0 + (size_t)(k >> 1) * W + (k & 1)) * ldx + c0);
+    for (int k = 0; k < 4; ++k)
+      in[k] = keep ? ld16<T>(x + (r0 + (size_t)(k >> 1) * W + (k & 1)) * ldx + c0) : ld16_nt<T>(x + (r0 + (size_t)(k >> 1) * W + (k & 1)) * ldx + c0);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       Vec16<T> o;
@@ -311,23 +313,41 @@ extern "C" int mi355_bn_act_pool2(const void* x, int ldx, const float* scale, co
   MI355_CHECK_ARG(C % epc == 0, "bn_act_pool2: C=%d must be a multiple of %d", C, epc);
   long long blocks = ((long long)N * (H / 2) * (W / 2) * (C / epc) + 255) / 256;
   if (blocks > 256 * 8) blocks = 256 * 8;
+  const int act_keep = 0;      // (see mi355_bn_act)
   return dispatch_dtype(dtype, "bn_act_pool2", [&](auto tag) {
     using T = decltype(tag);
     hipLaunchKernelGGL((bn_act_pool2_kernel<T>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx, scale, shift, (T*)y, ldy,
-                       (T*)p, ldp, N, H, W, C, act);
+                       (T*)p, ldp, N, H, W, C, act, act_keep);
     MI355_LAUNCH_CHECK();
     return (int)MI355_OK;
   });
 }
 
 // ---- backward ------------------------------------------------------------------------------------
+// Cache policy of the REDUCE passes' operand reads: the apply pass re-reads the same tensors right behind them, and with the
+// default policy finds part of them in the memory-side cache (end of round 3: -0.13 ms per step against streaming reads — round 2
+// had measured the opposite on a plan with more passes between the two; the apply passes' own reads stay streaming).
+// MI355_BN_REDUCE_NT=1 restores the streaming reads (A/B).
+static inline int bn_reduce_keeps() {
+  static const int nt = getenv("MI355_BN_REDUCE_NT") ? atoi(getenv("MI355_BN_REDUCE_NT")) : 0;
+  return nt ? 0 : 1;
+}
+
+// ... and of the APPLY passes' reads: the default policy as well since the end of round 3 (-0.13 ms per step; round 2 had measured
+// streaming reads ahead by 0.02).  MI355_BN_APPLY_NT=1 restores them (A/B).  The forward apply pass keeps its streaming read of the
+// raw convolution output (default policy there: +0.09 ms).
+static inline int bn_apply_keeps() {
+  static const int nt = getenv("MI355_BN_APPLY_NT") ? atoi(getenv("MI355_BN_APPLY_NT")) : 0;
+  return nt ? 0 : 1;
+}
+
 template <typename T> struct BnBwdReduceOp {
   static constexpr int NQ = 2;
   static constexpr bool WRITES = false;
   typedef float Acc;
   static constexpr int EPC = 16 / (int)sizeof(T);
   const T* dy; int lddy; const T* y; int ldy; const T* x; int ldx;
-  const float* mean; const float* invstd; const float* mscale; const float* mshift; int act;
+  const float* mean; const float* invstd; const float* mscale; const float* mshift; int act; int keep;
   float mu[EPC], is[EPC], ms[EPC], mt[EPC];
   __device__ void load_cols(int c0) {
 #pragma unroll
@@ -345,8 +365,13 @@ template <typename T> struct BnBwdReduceOp {
     // streaming loads (nontemporal): with the three BatchNorm passes reading their operands this way the step is 0.27 ms shorter
     // (reduce 4.15 -> 4.6 TB/s; the apply pass no longer finds the reduce pass's lines in the memory-side cache and is 1 % slower,
     // the sum wins) — A/B of all combinations in DESIGN.md section 4
-    in.g = ld16_nt<T>(dy + row * lddy + c0);
-    in.xv = ld16_nt<T>(x + row * ldx + c0);
+    if (keep) {        // leave the lines in the memory-side cache for the apply pass that re-reads them next (bn_reduce_keeps)
+      in.g = ld16<T>(dy + row * lddy + c0);
+      in.xv = ld16<T>(x + row * ldx + c0);
+    } else {
+      in.g = ld16_nt<T>(dy + row * lddy + c0);
+      in.xv = ld16_nt<T>(x + row * ldx + c0);
+    }
     if (act && y) in.yv = ld16<T>(y + row * ldy + c0);
     return in;
   }
@@ -373,7 +398,8 @@ extern "C" int mi355_bn_bwd_reduce(const void* dy, int lddy, const void* y, int 
   MI355_CHECK_ARG(dy && x && mean && invstd && partial && (!act || y || (mscale && mshift)), "bn_bwd_reduce: null pointer");
   return dispatch_dtype(dtype, "bn_bwd_reduce", [&](auto tag) {
     using T = decltype(tag);
-    BnBwdReduceOp<T> op{(const T*)dy, lddy, (const T*)y, ldy, (const T*)x, ldx, mean, invstd, mscale, mshift, act};
+    const int keep = bn_reduce_keeps();
+    BnBwdReduceOp<T> op{(const T*)dy, lddy, (const T*)y, ldy, (const T*)x, ldx, mean, invstd, mscale, mshift, act, keep};
     return rowred_launch<T>(op, M, C, partial, (hipStream_t)s);
   });
 }
@@ -421,7 +447,7 @@ template <typename T> struct BnBwdApplyOp {
   const T* dy; int lddy; const T* y; int ldy; const T* x; int ldx;
   const float* gamma; const float* mean; const float* invstd; const float* mscale; const float* mshift; const float* sums;
   T* dx; int lddx; T* dres; int lddres; T* dpost; int lddpost; int post_acc;
-  float invM; int C; int act;
+  float invM; int C; int act; int keep;
   float mu[EPC], is[EPC], k0[EPC], k1[EPC], gi[EPC], ms[EPC], mt[EPC];
   __device__ void load_cols(int c0) {
 #pragma unroll
@@ -439,8 +465,13 @@ template <typename T> struct BnBwdApplyOp {
   struct In { Vec16<T> g, xv, yv, pv; };
   __device__ In fetch(size_t row, int c0) const {
     In in;
-    in.g = ld16_nt<T>(dy + row * lddy + c0);       // (last reads of both: nontemporal)
-    in.xv = ld16_nt<T>(x + row * ldx + c0);
+    if (keep) {
+      in.g = ld16<T>(dy + row * lddy + c0);
+      in.xv = ld16<T>(x + row * ldx + c0);
+    } else {
+      in.g = ld16_nt<T>(dy + row * lddy + c0);       // (last reads of both: nontemporal)
+      in.xv = ld16_nt<T>(x + row * ldx + c0);
+    }
     if (act && y) in.yv = ld16<T>(y + row * ldy + c0);
     if (dpost && post_acc) in.pv = ld16<T>(dpost + row * lddpost + c0);
     return in;
@@ -481,10 +512,11 @@ extern "C" int mi355_bn_bwd_apply(const void* dy, int lddy, const void* y, int l
                                   float* dbias_partial, long long M, int C, int act, int dtype, mi355_stream_t s) {
   MI355_CHECK_ARG(dy && x && gamma && mean && invstd && sums && dx && (!act || y || (mscale && mshift)), "bn_bwd_apply: null pointer");
   const float invM = (float)(1.0 / (double)M);
+  const int apply_keep = bn_apply_keeps();
   return dispatch_dtype(dtype, "bn_bwd_apply", [&](auto tag) {
     using T = decltype(tag);
     BnBwdApplyOp<T> op{(const T*)dy, lddy, (const T*)y, ldy, (const T*)x, ldx, gamma, mean, invstd,
-                       mscale, mshift, sums, (T*)dx, lddx, (T*)dres, lddres, (T*)dpost, lddpost, post_acc, invM, C, act};
+                       mscale, mshift, sums, (T*)dx, lddx, (T*)dres, lddres, (T*)dpost, lddpost, post_acc, invM, C, act, apply_keep};
     return rowred_launch<T>(op, M, C, dbias_partial, (hipStream_t)s);
   });
 }
@@ -502,6 +534,7 @@ template <typename T> struct BnBwdPool2 {
   const T* dy; int lddy; const T* dp; int lddp; const T* x; int ldx;
   const float* mean; const float* invstd; const float* mscale; const float* mshift;
   int W, lrp, lwb;               // rp = 1 << lrp windows of a workgroup pass, W = (2 * rp) << lwb
+  int keep;                      // reduce pass: default cache policy (the apply pass re-reads the operands next); apply: streaming
   float mu[EPC], is[EPC], ms[EPC], mt[EPC];
   __device__ void load_common(int c0) {
 #pragma unroll
@@ -516,10 +549,10 @@ template <typename T> struct BnBwdPool2 {
     for (int b = 0; b < 4; ++b) p.pix[b] = (size_t)(2 * R + (b >> 1)) * W + 2 * wcol + (b & 1);
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      p.gv[b] = ld16_nt<T>(dy + p.pix[b] * lddy + c0);
-      p.xv[b] = ld16_nt<T>(x + p.pix[b] * ldx + c0);
+      p.gv[b] = keep ? ld16<T>(dy + p.pix[b] * lddy + c0) : ld16_nt<T>(dy + p.pix[b] * lddy + c0);
+      p.xv[b] = keep ? ld16<T>(x + p.pix[b] * ldx + c0) : ld16_nt<T>(x + p.pix[b] * ldx + c0);
     }
-    p.pv = ld16_nt<T>(dp + ((size_t)R * (W >> 1) + wcol) * lddp + c0);
+    p.pv = keep ? ld16<T>(dp + ((size_t)R * (W >> 1) + wcol) * lddp + c0) : ld16_nt<T>(dp + ((size_t)R * (W >> 1) + wcol) * lddp + c0);
   }
   // g[b]: the gradient reaching the activation of row b, ReLU-masked
   __device__ void grads(const Px& p, int e, float (&g)[4]) const {
@@ -622,6 +655,7 @@ template <typename T, typename Op> static void fill_pool2(Op& op, const void* dy
   op.dy = (const T*)dy; op.lddy = lddy; op.dp = (const T*)dp; op.lddp = lddp; op.x = (const T*)x; op.ldx = ldx;
   op.mean = mean; op.invstd = invstd; op.mscale = mscale; op.mshift = mshift;
   op.W = W; op.lrp = exact_log2(rp); op.lwb = exact_log2(W / (2 * rp));
+  op.keep = 0;
 }
 
 extern "C" int mi355_bn_bwd_reduce_pool2(const void* dy, int lddy, const void* dp, int lddp, const void* x, int ldx, const float* mean,
@@ -633,6 +667,7 @@ extern "C" int mi355_bn_bwd_reduce_pool2(const void* dy, int lddy, const void* d
     using T = decltype(tag);
     BnBwdReducePool2Op<T> op;
     fill_pool2<T>(op, dy, lddy, dp, lddp, x, ldx, mean, invstd, mscale, mshift, W, C);
+    op.keep = bn_reduce_keeps();
     return rowred_launch<T>(op, (long long)N * H * W, C, partial, (hipStream_t)s);
   });
 }
@@ -647,6 +682,7 @@ extern "C" int mi355_bn_bwd_apply_pool2(const void* dy, int lddy, const void* dp
     using T = decltype(tag);
     BnBwdApplyPool2Op<T> op;
     fill_pool2<T>(op, dy, lddy, dp, lddp, x, ldx, mean, invstd, mscale, mshift, W, C);
+    op.keep = bn_apply_keeps();
     op.gamma = gamma; op.sums = sums; op.dx = (T*)dx; op.lddx = lddx; op.invM = (float)(1.0 / (double)M); op.C = C;
     return rowred_launch<T>(op, M, C, nullptr, (hipStream_t)s);
   });

@@ -140,6 +140,12 @@ template <typename T> __device__ __forceinline__ Vec16<T> ld16(const T* p) {
   *reinterpret_cast<uint4*>(&r) = *reinterpret_cast<const uint4*>(p);
   return r;
 }
+// (the same load under a name the per-file `#define ld16 ld16_nt` of the streaming kernels does not capture)
+template <typename T> __device__ __forceinline__ Vec16<T> ld16_plain(const T* p) {
+  Vec16<T> r;
+  *reinterpret_cast<uint4*>(&r) = *reinterpret_cast<const uint4*>(p);
+  return r;
+}
 template <typename T> __device__ __forceinline__ void st16(T* p, const Vec16<T>& r) {
   *reinterpret_cast<uint4*>(p) = *reinterpret_cast<const uint4*>(&r);
 }

@@ -279,6 +279,7 @@ template <typename T, bool TWO> struct GateBnBwd {
   const float* dz; const T* g1; int ldg; const T* x1; int ldx;
   const float* scale_g; const float* shift_g; const float* scale_x; const float* shift_x;
   const float* mean_g; const float* invstd_g; const float* mean_x; const float* invstd_x; const float* w;
+  int keep;                      // reduce pass: default cache policy for g1 / x1 (the apply pass re-reads them next); apply: streaming
   float sg[EPC], sx[EPC], sh[EPC], mg[EPC], ig[EPC], mx[EPC], ix[EPC], wr[EPC];
   __device__ void load_common(int c0) {
 #pragma unroll
@@ -297,8 +298,13 @@ template <typename T, bool TWO> struct GateBnBwd {
   struct In { Vec16<T> gv, xv; float d; };
   __device__ In fetch(size_t row, int c0) const {
     In in;
-    in.gv = ld16_nt<T>(g1 + row * ldg + c0);
-    if constexpr (TWO) in.xv = ld16_nt<T>(x1 + row * ldx + c0);
+    if (keep) {
+      in.gv = ld16_plain<T>(g1 + row * ldg + c0);
+      if constexpr (TWO) in.xv = ld16_plain<T>(x1 + row * ldx + c0);
+    } else {
+      in.gv = ld16_nt<T>(g1 + row * ldg + c0);
+      if constexpr (TWO) in.xv = ld16_nt<T>(x1 + row * ldx + c0);
+    }
     in.d = dz[row];
     return in;
   }
@@ -378,6 +384,7 @@ template <typename T, typename Op> static void fill_gate_bn(Op& op, const float*
   op.scale_g = co[0]; op.shift_g = co[1]; op.mean_g = co[2]; op.invstd_g = co[3];
   op.scale_x = co[4]; op.shift_x = co[5]; op.mean_x = co[6]; op.invstd_x = co[7];
   op.w = w;
+  op.keep = 0;
 }
 
 extern "C" int mi355_gate_bn_bwd_reduce(const float* dz, const void* g1, int ldg, const void* x1, int ldx, const float* scale_g,
@@ -389,13 +396,16 @@ extern "C" int mi355_gate_bn_bwd_reduce(const float* dz, const void* g1, int ldg
   const float* co[8] = {scale_g, shift_g, mean_g, invstd_g, scale_x, shift_x, mean_x, invstd_x};
   return dispatch_dtype(dtype, "gate_bn_bwd_reduce", [&](auto tag) {
     using T = decltype(tag);
+    static const int nt = getenv("MI355_BN_REDUCE_NT") ? atoi(getenv("MI355_BN_REDUCE_NT")) : 0;      // (see bn.hip: bn_reduce_keeps)
     if (x1) {
       GateBnBwdReduceOp<T, true> op;
       fill_gate_bn<T>(op, dz, g1, ldg, x1, ldx, co, w);
+      op.keep = !nt;
       return rowred_launch<T>(op, M, C, partial, (hipStream_t)s);
     }
     GateBnBwdReduceOp<T, false> op;        // one normalised operand (quantity 2 of the partial rows stays zero)
     fill_gate_bn<T>(op, dz, g1, ldg, nullptr, 0, co, w);
+    op.keep = !nt;
     return rowred_launch<T>(op, M, C, partial, (hipStream_t)s);
   });
 }
@@ -410,8 +420,10 @@ extern "C" int mi355_gate_bn_bwd_apply(const float* dz, const void* g1, int ldg,
   const float* co[8] = {scale_g, shift_g, mean_g, invstd_g, scale_x, shift_x, mean_x, invstd_x};
   return dispatch_dtype(dtype, "gate_bn_bwd_apply", [&](auto tag) {
     using T = decltype(tag);
+    static const int apply_nt = getenv("MI355_BN_APPLY_NT") ? atoi(getenv("MI355_BN_APPLY_NT")) : 0;      // (see bn.hip: bn_apply_keeps)
     auto run = [&](auto op) {
       fill_gate_bn<T>(op, dz, g1, ldg, x1, ldx, co, w);
+      op.keep = !apply_nt;
       op.gamma_g = gamma_g; op.gamma_x = gamma_x; op.sums_g = sums_g; op.sums_x = sums_x;
       op.dg = (T*)dg1; op.lddg = lddg; op.dx = (T*)dx1; op.lddx = lddx; op.invM = (float)(1.0 / (double)M); op.C = C;
       return rowred_launch<T>(op, M, C, nullptr, (hipStream_t)s);

@@ -66,6 +66,13 @@ def profile_plan(plan, x, stream, reps=2):
     # plan forks the weight-gradient launches onto a side stream)
     fwd, bwd = plan._resolve(plan.pre + plan.fwd, stream), plan._resolve(plan.bwd, stream)
     agg = {}
+    # one untimed replay first: the side-stream launches run on THIS stream here for the first time (vgg16_bn 512 x 512: the
+    # stem's weight gradient took 60 ms in its first single-stream execution and 0.19 ms ever after)
+    for i, (fn, args, name, l) in enumerate(list(fwd) + list(bwd)):
+        rc = fn(x.data_ptr(), *args[1:]) if i == 0 else fn(*args)
+        if rc:
+            raise RuntimeError(f"{name} failed rc={rc}")
+    torch.cuda.synchronize()
     for _ in range(reps):
         recs = []
         for i, (fn, args, name, l) in enumerate(list(fwd) + list(bwd)):

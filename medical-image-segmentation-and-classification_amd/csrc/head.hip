@@ -104,58 +104,132 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
 // atomics.  Algorithmic bytes: forward O*I*4 read; backward O*I*4 read (dx) + O*I*4 written (dW).
 constexpr int LIN_BT = 16;      // batch rows per pass
 
-// y[b][o] = act(sum_i x[b][i] w[o][i] + bias[o]): one wave per output row o, lanes stride the row in float4s
+// y[b][o] = act(sum_i x[b][i] w[o][i] + bias[o]): a wave owns LIN_R consecutive output rows and strides them in float4s, so a
+// 16-byte piece of every batch row (L1 / L2 traffic: 16 loads) meets LIN_R weight loads instead of one — with one row per wave the
+// kernel moved 17 bytes through the L1 per weight byte and ran at 0.66 TB/s (scripts/linear_bench.py).
+constexpr int LIN_R = 4;
+typedef float lin_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 lin_ldnt(const float4* p) {      // streaming 16-byte load / store of the weight matrix
+  const lin_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const lin_f32x4*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void lin_stnt(float4* p, const float4& a) {
+  const lin_f32x4 v = {a.x, a.y, a.z, a.w};
+  __builtin_nontemporal_store(v, reinterpret_cast<lin_f32x4*>(p));
+}
 __global__ __launch_bounds__(256) void linear_fwd_wide_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ bias, float* __restrict__ y, int B, int I,
                                                               int O, int relu) {
-  const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  // a workgroup owns LIN_R output rows; its four waves take a quarter of the columns each (1024 workgroups for O = 4096: with one
+  // wave per SIMD the 98 dependent load-then-multiply trips of a row were latency-bound) and meet in LDS
+  __shared__ float red[4][LIN_R * LIN_BT];
+  const int o0 = blockIdx.x * LIN_R, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b0 = blockIdx.y * LIN_BT, nb = min(LIN_BT, B - b0);
-  if (o >= O) return;
-  float acc[LIN_BT];
+  float acc[LIN_R][LIN_BT];
 #pragma unroll
-  for (int b = 0; b < LIN_BT; ++b) acc[b] = 0.f;
-  const float4* wr = reinterpret_cast<const float4*>(w + (size_t)o * I);
+  for (int r = 0; r < LIN_R; ++r)
+#pragma unroll
+    for (int b = 0; b < LIN_BT; ++b) acc[r][b] = 0.f;
   const int I4 = I >> 2;
-  for (int i = lane; i < I4; i += 64) {
-    const float4 wv = wr[i];
+  const int chunk = ((I4 + 3) / 4 + 63) / 64 * 64;              // columns (in float4s) per wave, a multiple of the wave's stride
+  const int i_end = min(I4, (wave + 1) * chunk);
+  const float4* wr[LIN_R];
+#pragma unroll
+  for (int r = 0; r < LIN_R; ++r) wr[r] = reinterpret_cast<const float4*>(w + (size_t)min(o0 + r, O - 1) * I);      // (rows past the end: clamped, not stored)
+  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)b0 * I);
+  // the next trip's weight pieces are requested before this trip's multiply-adds (columns past the end: clamped, weights zeroed)
+  int i = wave * chunk + lane;
+  float4 wv[LIN_R];
+#pragma unroll
+  for (int r = 0; r < LIN_R; ++r) wv[r] = lin_ldnt(wr[r] + min(i, I4 - 1));
+  for (; i < i_end; i += 64) {
+    float4 wn[LIN_R];
+    const int inx = min(i + 64, I4 - 1);
+#pragma unroll
+    for (int r = 0; r < LIN_R; ++r) wn[r] = lin_ldnt(wr[r] + inx);
 #pragma unroll
     for (int b = 0; b < LIN_BT; ++b) {
-      if (b < nb) {
-        const float4 xv = reinterpret_cast<const float4*>(x + (size_t)(b0 + b) * I)[i];
-        acc[b] += wv.x * xv.x + wv.y * xv.y + wv.z * xv.z + wv.w * xv.w;
-      }
+      const float4 xv = xr[(size_t)min(b, nb - 1) * I4 + i];      // (unconditional, clamped: a guarded load is waited for before the next)
+#pragma unroll
+      for (int r = 0; r < LIN_R; ++r) acc[r][b] += wv[r].x * xv.x + wv[r].y * xv.y + wv[r].z * xv.z + wv[r].w * xv.w;
     }
+#pragma unroll
+    for (int r = 0; r < LIN_R; ++r) wv[r] = wn[r];
   }
 #pragma unroll
-  for (int b = 0; b < LIN_BT; ++b) {
-    const float v = wave_sum(acc[b]);
-    if (lane == 0 && b < nb) {
-      const float r = v + (bias ? bias[o] : 0.f);
-      y[(size_t)(b0 + b) * O + o] = relu ? fmaxf(r, 0.f) : r;
+  for (int r = 0; r < LIN_R; ++r)
+#pragma unroll
+    for (int b = 0; b < LIN_BT; ++b) {
+      const float v = wave_sum(acc[r][b]);
+      if (lane == 0) red[wave][r * LIN_BT + b] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < LIN_R * LIN_BT) {
+    const int r = threadIdx.x / LIN_BT, b = threadIdx.x - r * LIN_BT;
+    if (b < nb && o0 + r < O) {
+      const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]) + (bias ? bias[o0 + r] : 0.f);
+      y[(size_t)(b0 + b) * O + o0 + r] = relu ? fmaxf(t, 0.f) : t;
     }
   }
+}
+
+// The backward kernels keep the masked output gradient of their rows, g[o][b] = dy[b][o] * (relu ? y[b][o] > 0 : 1), in LDS
+// (16 floats per output row, read back as four broadcast ds_read_b128): fetched per output row through wave-uniform global
+// loads, 32 dependent scalar loads sat in front of every weight row (dx 0.85 TB/s, dW 1.4 TB/s).
+constexpr int LIN_GROWS = 128;      // output rows per workgroup of the dx kernel (an 8 KB tile of g)
+__device__ __forceinline__ void linear_stage_g(float (*lg)[LIN_BT], const float* __restrict__ y, const float* __restrict__ dy, int b0,
+                                               int nb, int o0, int rows, int O, int relu) {
+  for (int idx = threadIdx.x; idx < rows * LIN_BT; idx += blockDim.x) {
+    const int r = idx / LIN_BT, b = idx - r * LIN_BT;
+    float g = 0.f;
+    if (b < nb) {
+      g = dy[(size_t)(b0 + b) * O + o0 + r];
+      if (relu && !(y[(size_t)(b0 + b) * O + o0 + r] > 0.f)) g = 0.f;
+    }
+    lg[r][b] = g;
+  }
+  __syncthreads();
 }
 
 // partial dx: part[split][b][i] = sum_{o in split} g[b][o] w[o][i]; a thread owns four consecutive i
 __global__ __launch_bounds__(256) void linear_dx_wide_kernel(const float* __restrict__ w, const float* __restrict__ y,
                                                              const float* __restrict__ dy, float* __restrict__ part, int B, int I,
                                                              int O, int relu, int o_per_split) {
+  __shared__ __attribute__((aligned(16))) float lg[LIN_GROWS][LIN_BT];
   const int i4 = blockIdx.x * 256 + threadIdx.x;
   const int b0 = blockIdx.z * LIN_BT, nb = min(LIN_BT, B - b0);
-  const int o0 = blockIdx.y * o_per_split, o1 = min(O, o0 + o_per_split);
+  const int o0 = blockIdx.y * o_per_split, rows = min(o_per_split, O - o0);
+  linear_stage_g(lg, y, dy, b0, nb, o0, rows, O, relu);
   if (i4 * 4 >= I) return;
   float4 acc[LIN_BT];
 #pragma unroll
   for (int b = 0; b < LIN_BT; ++b) acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int o = o0; o < o1; ++o) {
-    const float4 wv = reinterpret_cast<const float4*>(w + (size_t)o * I)[i4];
+  const float4* wp = reinterpret_cast<const float4*>(w + (size_t)o0 * I) + i4;
+  const size_t stride = (size_t)(I >> 2);
+  int r = 0;
+  for (; r + 4 <= rows; r += 4) {                    // four weight rows in flight
+    float4 wv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wv[u] = lin_ldnt(wp + (size_t)(r + u) * stride);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int q = 0; q < LIN_BT / 4; ++q) {
+        const float4 g = *reinterpret_cast<const float4*>(&lg[r + u][4 * q]);
+        const float gs[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float4& a = acc[4 * q + k];
+          a.x += gs[k] * wv[u].x; a.y += gs[k] * wv[u].y; a.z += gs[k] * wv[u].z; a.w += gs[k] * wv[u].w;
+        }
+      }
+  }
+  for (; r < rows; ++r) {
+    const float4 wv = wp[(size_t)r * stride];
 #pragma unroll
     for (int b = 0; b < LIN_BT; ++b) {
-      if (b < nb) {
-        float g = dy[(size_t)(b0 + b) * O + o];
-        if (relu && !(y[(size_t)(b0 + b) * O + o] > 0.f)) g = 0.f;
-        acc[b].x += g * wv.x; acc[b].y += g * wv.y; acc[b].z += g * wv.z; acc[b].w += g * wv.w;
-      }
+      const float g = lg[r][b];
+      acc[b].x += g * wv.x; acc[b].y += g * wv.y; acc[b].z += g * wv.z; acc[b].w += g * wv.w;
     }
   }
 #pragma unroll
@@ -175,39 +249,55 @@ __global__ void linear_dx_fold_kernel(const float* __restrict__ part, float* __r
 __global__ __launch_bounds__(256) void linear_dw_wide_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                              const float* __restrict__ dy, float* __restrict__ dw,
                                                              float* __restrict__ db, int B, int I, int O, int relu, float beta) {
+  __shared__ __attribute__((aligned(16))) float lg[64][LIN_BT];
   const int i4 = blockIdx.x * 256 + threadIdx.x;
-  const int o0 = blockIdx.y * 64, o1 = min(O, o0 + 64);
+  const int o0 = blockIdx.y * 64, rows = min(64, O - o0);
   const bool live = i4 * 4 < I;
+  const int i4c = live ? i4 : 0;
   for (int b0 = 0; b0 < B; b0 += LIN_BT) {                     // (B <= 16 in every configuration: one trip)
     const int nb = min(LIN_BT, B - b0);
+    if (b0) __syncthreads();
+    linear_stage_g(lg, y, dy, b0, nb, o0, rows, O, relu);
     float4 xv[LIN_BT];
 #pragma unroll
-    for (int b = 0; b < LIN_BT; ++b)
-      xv[b] = (live && b < nb) ? reinterpret_cast<const float4*>(x + (size_t)(b0 + b) * I)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int o = o0; o < o1; ++o) {
+    for (int b = 0; b < LIN_BT; ++b) xv[b] = reinterpret_cast<const float4*>(x + (size_t)(b0 + min(b, nb - 1)) * I)[i4c];      // (rows past nb meet g == 0)
+    const float keep = (b0 == 0) ? beta : 1.f;                  // later batch chunks accumulate onto the first
+    for (int r = 0; r < rows; ++r) {
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       float sb = 0.f;
 #pragma unroll
-      for (int b = 0; b < LIN_BT; ++b) {
-        if (b < nb) {
-          float g = dy[(size_t)(b0 + b) * O + o];
-          if (relu && !(y[(size_t)(b0 + b) * O + o] > 0.f)) g = 0.f;
-          acc.x += g * xv[b].x; acc.y += g * xv[b].y; acc.z += g * xv[b].z; acc.w += g * xv[b].w;
-          sb += g;
+      for (int q = 0; q < LIN_BT / 4; ++q) {
+        const float4 g = *reinterpret_cast<const float4*>(&lg[r][4 * q]);
+        const float gs[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float4& v = xv[4 * q + k];
+          acc.x += gs[k] * v.x; acc.y += gs[k] * v.y; acc.z += gs[k] * v.z; acc.w += gs[k] * v.w;
+          sb += gs[k];
         }
       }
-      const float keep = (b0 == 0) ? beta : 1.f;                // later batch chunks accumulate onto the first
       if (live) {
-        float4* p = reinterpret_cast<float4*>(dw + (size_t)o * I) + i4;
+        float4* p = reinterpret_cast<float4*>(dw + (size_t)(o0 + r) * I) + i4;
         if (keep != 0.f) {
           const float4 old = *p;
           acc.x += keep * old.x; acc.y += keep * old.y; acc.z += keep * old.z; acc.w += keep * old.w;
         }
-        *p = acc;
+        lin_stnt(p, acc);
       }
-      if (db && blockIdx.x == 0 && threadIdx.x == 0) db[o] = (keep != 0.f ? keep * db[o] : 0.f) + sb;
+      if (db && blockIdx.x == 0 && threadIdx.x == 0) db[o0 + r] = (keep != 0.f ? keep * db[o0 + r] : 0.f) + sb;
     }
   }
+}
+
+// output-row ranges of the dx kernel: enough workgroups to fill the chip (the 4096 x 4096 layer has four column blocks), at most
+// LIN_GROWS rows each
+static inline int linear_dx_splits(int I, int O) {
+  const int iblocks = ceil_div(I / 4, 256);
+  int splits = ceil_div(768, iblocks);
+  if (splits > 64) splits = 64;                       // (every range costs a B x I partial: written, then folded)
+  if (splits < ceil_div(O, LIN_GROWS)) splits = ceil_div(O, LIN_GROWS);
+  if (splits > O) splits = O;
+  return splits;
 }
 
 static inline bool linear_wide(int B, int I, int O) { return I % 4 == 0 && (long long)I * O >= (1 << 20) && B >= 1; }
@@ -216,8 +306,8 @@ extern "C" int mi355_linear_fwd(const float* x, const float* w, const float* bia
                                 mi355_stream_t s) {
   MI355_CHECK_ARG(x && w && y, "linear_fwd: null pointer");
   if (linear_wide(B, I, O))
-    hipLaunchKernelGGL(linear_fwd_wide_kernel, dim3(ceil_div(O, 4), ceil_div(B, LIN_BT)), dim3(256), 0, (hipStream_t)s, x, w, bias, y, B,
-                       I, O, relu);
+    hipLaunchKernelGGL(linear_fwd_wide_kernel, dim3(ceil_div(O, LIN_R), ceil_div(B, LIN_BT)), dim3(256), 0, (hipStream_t)s, x, w, bias,
+                       y, B, I, O, relu);
   else
     hipLaunchKernelGGL(linear_fwd_kernel, dim3(ceil_div((long long)B * O, 4)), dim3(256), 0, (hipStream_t)s, x, w, bias, y, B, I, O,
                        relu);
@@ -228,7 +318,7 @@ extern "C" int mi355_linear_fwd(const float* x, const float* w, const float* bia
 /* scratch floats mi355_linear_bwd needs for the input gradient of a wide layer (0: none) */
 extern "C" int mi355_linear_bwd_scratch(int B, int I, int O) {
   if (!linear_wide(B, I, O)) return 0;
-  const long long n = (long long)16 * B * I;
+  const long long n = (long long)linear_dx_splits(I, O) * B * I;
   return n > 0x7fffffff ? -1 : (int)n;
 }
 
@@ -270,7 +360,7 @@ extern "C" int mi355_linear_bwd(const float* x, const float* w, const float* y, 
   if (linear_wide(B, I, O)) {
     if (dx) {
       MI355_CHECK_ARG(scratch, "linear_bwd: a wide layer needs mi355_linear_bwd_scratch(B, I, O) floats of scratch for dx");
-      const int splits = 16, ops = ceil_div(O, splits);
+      const int splits0 = linear_dx_splits(I, O), ops = ceil_div(O, splits0), splits = ceil_div(O, ops);
       hipLaunchKernelGGL(linear_dx_wide_kernel, dim3(ceil_div(I / 4, 256), splits, ceil_div(B, LIN_BT)), dim3(256), 0, (hipStream_t)s, w,
                          y, dy, scratch, B, I, O, relu, ops);
       hipLaunchKernelGGL(linear_dx_fold_kernel, dim3(ceil_div((long long)B * I, 256) > 2048 ? 2048 : ceil_div((long long)B * I, 256)),

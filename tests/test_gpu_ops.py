@@ -602,7 +602,7 @@ def test_heads_and_losses():
         yd = torch.empty(b, o, device=DEV)
         lib.mi355_linear_fwd(dev(x.detach()), dev(w.detach()), dev(bias.detach()), yd, b, i, o, relu)
         need = lib.mi355_linear_bwd_scratch(b, i, o)
-        assert need == 16 * b * i
+        assert need % (b * i) == 0 and need // (b * i) >= 4          # one partial per output-row range (enough ranges to fill the chip)
         scratch = torch.empty(need, device=DEV)
         dx = torch.full((b, i), float("nan"), device=DEV); dw = torch.ones(o, i, device=DEV); db = torch.ones(o, device=DEV)
         lib.mi355_linear_bwd(dev(x.detach()), dev(w.detach()), yd, dev(dy), dx, dw, db, b, i, o, relu, 1.0, scratch)

@@ -33,6 +33,7 @@ FUSE_HEAD = os.environ.get("MI355_FUSE_HEAD", "1") != "0"           # relu(bn(.)
 STEM_IM2COL = os.environ.get("MI355_STEM_IM2COL", "1") != "0"       # Conv2d(3, Co, 3, 1, 1) on the network input as a pointwise convolution over its 3 x 3 patches
 SIDE_COLSUM = os.environ.get("MI355_SIDE_COLSUM", "1") != "0"       # psi / head weight-gradient folds (they only feed the optimiser) leave the main stream
 BN_ACT_WINDOWS = os.environ.get("MI355_BN_ACT_WINDOWS", "1") != "0"  # plain BatchNorm apply passes on even images run the window-ordered kernel (mi355_bn_act_pool2 without a pooled output)
+STATIC_PACKS = os.environ.get("MI355_STATIC_PACKS", "1") != "0"     # weight packs of FROZEN parameters are refreshed when the parameters change, not every step
 FUSE_RESIDUAL = os.environ.get("MI355_FUSE_RESIDUAL", "1") != "0"   # RRCNN_block's x0 + RCNN(x0) inside the last BatchNorm apply pass (A/B switch)
 
 
@@ -127,6 +128,8 @@ class Plan:
         self.dtype = b.dtype
         self.training = b.training
         self.pre, self.fwd, self.bwd = b.pre, b.fwd, b.bwd
+        self.static_pack, self.static_params, self._static_sig = b.static_pack, b.static_params, None
+        self.flat_p = b.engine.flat_p
         self.keep = b.keep
         self.acts = b.acts                # [(kind, handles...)] in forward order: activations at the network's kinks (tests / diagnostics)
         self.input = b.input
@@ -242,8 +245,19 @@ class Plan:
             if rc:
                 raise RuntimeError(f"{name} failed (rc={rc}): {lib.raw('mi355_last_error')().decode()}")
 
+    def refresh_static_packs(self, stream):
+        """Weight packs of frozen parameters: one launch when they changed (load_state_dict / in-place edits bump the
+        parameters' version counters, a data-parallel state sync the flat buffer's), nothing otherwise."""
+        if self.static_pack is None:
+            return
+        sig = (self.flat_p._version, sum(p._version for p in self.static_params))
+        if sig != self._static_sig:
+            self._run(self._resolve([self.static_pack], stream))
+            self._static_sig = sig
+
     def run_forward(self, stream, x_ptr=None):
         """pre + forward launches; ``x_ptr``: the caller's NCHW fp32 input (read in place by the first launch)."""
+        self.refresh_static_packs(stream)
         calls = self.bind(stream)[0]
         key = int(stream or 0)
         if self.replay_in_c:
@@ -1326,12 +1340,25 @@ class Builder:
                 raise NotImplementedError("network input read both by a 3x3 stem (as im2col) and by another layer")
             col = [l for l in self.pre if l.name == "mi355_pack_input_im2col3"]
             self.pre = col + [l for l in self.pre if l is not self._xin_pack and l.name != "mi355_pack_input_im2col3"]
+        self.static_pack, self.static_params = None, []
         if self._pack_table:
-            rows = [[w.data_ptr(), wf.data_ptr(), wb.data_ptr() if wb is not None else 0, co, ci, cip, taps, tr,
-                     sc.data_ptr() if sc is not None else 0] for (w, wf, wb, co, ci, cip, taps, tr, sc) in self._pack_table]
-            table = torch.tensor(rows, dtype=torch.int64).to(self.device)
-            self.keep.append(table)
-            self.pre.append(Launch("mi355_pack_conv_weights_batched", table, len(rows), len(rows[0]), self.code))
+            def pack_launch(entries):
+                rows = [[w.data_ptr(), wf.data_ptr(), wb.data_ptr() if wb is not None else 0, co, ci, cip, taps, tr,
+                         sc.data_ptr() if sc is not None else 0] for (w, wf, wb, co, ci, cip, taps, tr, sc) in entries]
+                table = torch.tensor(rows, dtype=torch.int64).to(self.device)
+                self.keep.append(table)
+                return Launch("mi355_pack_conv_weights_batched", table, len(rows), len(rows[0]), self.code)
+            # a training plan re-packs what the optimiser changes every step; the packs of FROZEN parameters (the ResNet-50
+            # encoder of ResnetUnet.py:60-66, a classifier's backbone in stage 1 of helpers.py:246-262) are refreshed only
+            # when those parameters change (Plan.refresh_static_packs watches their version counters).  Packs with an
+            # eval-mode BatchNorm scale folded in depend on running statistics that kernels update: they stay per-run.
+            frozen = [e for e in self._pack_table if STATIC_PACKS and self.want_grad and not e[0].requires_grad and e[8] is None]
+            live = [e for e in self._pack_table if not any(e is f for f in frozen)]
+            if frozen:
+                self.static_pack = pack_launch(frozen)
+                self.static_params = [e[0] for e in frozen]
+            if live:
+                self.pre.append(pack_launch(live))
         for r in reversed(self._rules):
             r()
         assert not self._pending_wgrad, "a shared convolution's weight gradient is still waiting for an application's backward"

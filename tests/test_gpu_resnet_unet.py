@@ -107,3 +107,36 @@ def test_side_stream_gradients_are_bit_identical(monkeypatch, freeze):
     for k in res[0]:
         assert torch.equal(res[0][k], res[1][k]), k
     assert all(np.isfinite(float(v.abs().max())) for v in res[0].values())
+
+
+def test_frozen_weight_packs_follow_the_parameters():
+    """The packed copies of FROZEN convolution weights (ResnetUnet.py:60-66: the ResNet-50 encoder) are refreshed when those
+    parameters change, not every step (graph.py: STATIC_PACKS; Plan.refresh_static_packs watches the version counters).  An
+    in-place edit and a load_state_dict between two forwards of the SAME plan must both be seen, and steps in between must not
+    re-pack."""
+    m, sd = _model(torch.float32)
+    x, _ = otrain.closed_form_input(2, 64)
+    xd = x.to(DEV)
+    out1 = m(xd)
+    plan = out1._mi355_plan
+    assert plan.static_pack is not None and len(plan.static_params) > 40 and not any(p.requires_grad for p in plan.static_params)
+    assert all(not any(a is plan.static_pack.args[0] for a in l.args) for l in plan.pre)           # not part of the per-step launches
+    o1 = out1.detach().clone()
+    sig = plan._static_sig
+    o1b = m(xd).detach().clone()
+    assert plan._static_sig == sig and torch.equal(o1, o1b)                                         # nothing changed: nothing re-packed
+    w = dict(m.named_parameters())["encoder2.0.conv1.weight"]
+    assert not w.requires_grad
+    with torch.no_grad():
+        w.mul_(1.25)                                                                               # in-place edit of a frozen weight
+    o2 = m(xd).detach().clone()
+    assert plan._static_sig != sig and not torch.equal(o1, o2)
+    m2, _ = _model(torch.float32)
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    sd2["encoder2.0.conv1.weight"] = sd2["encoder2.0.conv1.weight"] * 1.25
+    m2.load_state_dict(sd2)
+    o2_ref = m2(xd).detach()
+    assert float((o2 - o2_ref).abs().max()) <= 1e-6 * float(o2_ref.abs().max())
+    m.load_state_dict(sd)                                                                          # back to the original weights
+    o3 = m(xd).detach()
+    assert float((o3 - o1).abs().max()) <= 1e-6 * float(o1.abs().max())

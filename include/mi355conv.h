@@ -171,6 +171,11 @@ int mi355_bn_act(const void* x, int ldx, const float* scale, const float* shift,
  * apply passes on even images (a thread owns a 2 x 2 window: measured ≈8 % faster than the row-ordered mi355_bn_act). */
 int mi355_bn_act_pool2(const void* x, int ldx, const float* scale, const float* shift, void* y, int ldy, void* p, int ldp,
                        int N, int H, int W, int C, int act, int dtype, mi355_stream_t s);
+/* mi355_bn_act's forms WITHOUT a second normalised operand (plain, or with the residual `res` added before the activation — act
+ * bit 1: after it, the recurrent block's x + relu(bn(.)), R2AttU_Net.py:44) in the window order of mi355_bn_act_pool2: the same
+ * values, ≈8 % faster on even images. */
+int mi355_bn_act_windows(const void* x, int ldx, const float* scale, const float* shift, const void* res, int ldr, void* y, int ldy,
+                         int N, int H, int W, int C, int act, int dtype, mi355_stream_t s);
 /* Backward reductions for y = act(bn(x) [+ other]) given dL/dy:
  * partial sums of g and g*xhat per channel, g = dy * (y > 0 if act).  When `y` is NULL the ReLU mask
  * is recomputed as x*mscale[c]+mshift[c] > 0 (the forward's own coefficients), which saves reading

@@ -265,7 +265,8 @@ extern "C" int mi355_bn_act(const void* x, int ldx, const float* scale, const fl
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_pool2_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, T* __restrict__ y, int ldy,
-                                                           T* __restrict__ p, int ldp, int N, int H, int W, int C, int act, int keep) {
+                                                           T* __restrict__ p, int ldp, int N, int H, int W, int C, int act, int keep,
+                                                           const T* __restrict__ res = nullptr, int ldr = 0) {
   constexpr int EPC = 16 / (int)sizeof(T);
   const int cp = C / EPC, Ho = H >> 1, Wo = W >> 1;
   const long long total = (long long)N * Ho * Wo * cp;
@@ -283,13 +284,20 @@ __global__ __launch_bounds__(256) void bn_act_pool2_kernel(const T* __restrict__
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       in[k] = keep ? ld16<T>(x + (r0 + (size_t)(k >> 1) * W + (k & 1)) * ldx + c0) : ld16_nt<T>(x + (r0 + (size_t)(k >> 1) * W + (k & 1)) * ldx + c0);
+    Vec16<T> rs[4];
+    if (res) {       // (mi355_bn_act's residual operand: added before the activation, or after it when act bit 1 is set)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) rs[k] = ld16<T>(res + (r0 + (size_t)(k >> 1) * W + (k & 1)) * ldr + c0);
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       Vec16<T> o;
 #pragma unroll
       for (int e = 0; e < EPC; ++e) {
         float v = __builtin_fmaf(to_f32<T>(in[k].v[e]), sc[e], sh[e]);
+        if (res && !(act & 2)) v += to_f32<T>(rs[k].v[e]);
         if (act & 1) v = fmaxf(v, 0.f);
+        if (res && (act & 2)) v += to_f32<T>(rs[k].v[e]);
         o.v[e] = from_f32<T>(v);
         const float r = to_f32<T>(o.v[e]);
         m[e] = k == 0 ? r : fmaxf(m[e], r);
@@ -318,6 +326,24 @@ extern "C" int mi355_bn_act_pool2(const void* x, int ldx, const float* scale, co
     using T = decltype(tag);
     hipLaunchKernelGGL((bn_act_pool2_kernel<T>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx, scale, shift, (T*)y, ldy,
                        (T*)p, ldp, N, H, W, C, act, act_keep);
+    MI355_LAUNCH_CHECK();
+    return (int)MI355_OK;
+  });
+}
+
+// mi355_bn_act's plain and residual forms (no second normalised operand) in the window order of the kernel above, on even images
+extern "C" int mi355_bn_act_windows(const void* x, int ldx, const float* scale, const float* shift, const void* res, int ldr, void* y,
+                                    int ldy, int N, int H, int W, int C, int act, int dtype, mi355_stream_t s) {
+  MI355_CHECK_ARG(x && scale && shift && y && N > 0, "bn_act_windows: bad arguments");
+  MI355_CHECK_ARG(H % 2 == 0 && W % 2 == 0, "bn_act_windows: %d x %d is not divisible into 2 x 2 groups", H, W);
+  const int epc = dtype_is_2byte(dtype) ? 8 : 4;
+  MI355_CHECK_ARG(C % epc == 0, "bn_act_windows: C=%d must be a multiple of %d", C, epc);
+  long long blocks = ((long long)N * (H / 2) * (W / 2) * (C / epc) + 255) / 256;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  return dispatch_dtype(dtype, "bn_act_windows", [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((bn_act_pool2_kernel<T>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx, scale, shift, (T*)y, ldy,
+                       (T*)nullptr, 0, N, H, W, C, act, 0, (const T*)res, ldr);
     MI355_LAUNCH_CHECK();
     return (int)MI355_OK;
   });

@@ -34,6 +34,7 @@ STEM_IM2COL = os.environ.get("MI355_STEM_IM2COL", "1") != "0"       # Conv2d(3, 
 SIDE_COLSUM = os.environ.get("MI355_SIDE_COLSUM", "1") != "0"       # psi / head weight-gradient folds (they only feed the optimiser) leave the main stream
 BN_ACT_WINDOWS = os.environ.get("MI355_BN_ACT_WINDOWS", "1") != "0"  # plain BatchNorm apply passes on even images run the window-ordered kernel (mi355_bn_act_pool2 without a pooled output)
 STATIC_PACKS = os.environ.get("MI355_STATIC_PACKS", "1") != "0"     # weight packs of FROZEN parameters are refreshed when the parameters change, not every step
+BN_ACT_WINDOWS_RES = os.environ.get("MI355_BN_ACT_WINDOWS_RES", "1") != "0"   # ... and the passes with a residual operand
 FUSE_RESIDUAL = os.environ.get("MI355_FUSE_RESIDUAL", "1") != "0"   # RRCNN_block's x0 + RCNN(x0) inside the last BatchNorm apply pass (A/B switch)
 
 
@@ -1328,11 +1329,15 @@ class Builder:
             # peephole meanwhile): the window-ordered kernel without a pooled output — the same values, ≈8 % faster
             for i, l in enumerate(self.fwd):
                 a_ = l.args
-                if l.name == "mi355_bn_act" and a_[4] is None and a_[8] is None and isinstance(a_[10], T) and a_[10].H % 2 == 0 \
+                if l.name == "mi355_bn_act" and a_[4] is None and isinstance(a_[10], T) and a_[10].H % 2 == 0 \
                         and a_[10].W % 2 == 0 and a_[12] == a_[10].M:
                     t = a_[10]
-                    self.fwd[i] = Launch("mi355_bn_act_pool2", a_[0], a_[1], a_[2], a_[3], t, t.ld, None, 0, t.N, t.H, t.W, t.C, a_[14],
-                                         self.code, nbytes=l.bytes)
+                    if a_[8] is None:
+                        self.fwd[i] = Launch("mi355_bn_act_pool2", a_[0], a_[1], a_[2], a_[3], t, t.ld, None, 0, t.N, t.H, t.W, t.C, a_[14],
+                                             self.code, nbytes=l.bytes)
+                    elif BN_ACT_WINDOWS_RES:      # residual added before / after the activation (ResNet.py:43, R2AttU_Net.py:44)
+                        self.fwd[i] = Launch("mi355_bn_act_windows", a_[0], a_[1], a_[2], a_[3], a_[8], a_[9], t, t.ld, t.N, t.H, t.W, t.C,
+                                             a_[14], self.code, nbytes=l.bytes)
         if getattr(self, "_xcol", None) is not None:
             # the stem reads the im2col of the input: that pack takes the place of the plain one as launch 0 (the launch whose source
             # pointer Plan.run_forward patches to the caller's tensor)

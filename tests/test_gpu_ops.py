@@ -179,6 +179,15 @@ def test_bn_act_with_fused_maxpool_is_bit_identical_to_the_two_passes(dtype, act
     lib.mi355_bn_act_pool2(xd, c, dev(sc), dev(sh), y.data_ptr() + 8 * es, c + 8, None, 0, n, h, w, c, act, code)
     torch.cuda.synchronize()
     assert torch.equal(y.cpu(), outs[0][0])
+    # mi355_bn_act_windows: the same kernel with mi355_bn_act's residual operand (before the activation / after it: act bit 1)
+    r = q(torch.randn(n, c, h, w, generator=g), dtype)
+    rd = to_nhwc(r, dtype)
+    for a2 in (act, act | 2):
+        ya = torch.zeros(n, h, w, c, dtype=dtype, device=DEV); yb = torch.zeros_like(ya)
+        lib.mi355_bn_act(xd, c, dev(sc), dev(sh), None, 0, None, None, rd, c, ya, c, n * h * w, c, a2, code)
+        lib.mi355_bn_act_windows(xd, c, dev(sc), dev(sh), rd, c, yb, c, n, h, w, c, a2, code)
+        torch.cuda.synchronize()
+        assert torch.equal(ya, yb), a2
 
 
 @pytest.mark.parametrize("dtype", DT)

@@ -205,7 +205,8 @@ int mi355_bn_bwd_apply(const void* dy, int lddy, const void* y, int ldy, const v
  * AttentionUNet.py:61,89-95): dp, the gradient of the POOLED tensor [N][H/2][W/2][C], is added on the fly to the pixels that are
  * the first maximum of their window (torch's tie rule, the activation recomputed from x with mscale / mshift exactly as the
  * forward rounded it), so mi355_maxpool_bwd's pass over dy is not run: g = relu'(.) * (dy + [first max] * dp).  partial / sums /
- * dx as in mi355_bn_bwd_reduce / _apply with act = 1 and no y.  mi355_bn_bwd_pool2_ok: 1 when the window-ordered pass covers the
+ * dx as in mi355_bn_bwd_reduce / _apply with act = 1 and no y.  dy == NULL: the pooling is the activation's only consumer (VGG.py),
+ * g = relu'(.) * [first max] * dp.  mi355_bn_bwd_pool2_ok: 1 when the window-ordered pass covers the
  * geometry (C / (16 / element size) a power of two <= 32, W a power-of-two multiple of 512 / that), else use the separate passes. */
 int mi355_bn_bwd_pool2_ok(int H, int W, int C, int dtype);
 int mi355_bn_bwd_reduce_pool2_rows(long long M);      /* partial rows mi355_bn_bwd_reduce_pool2 can leave non-zero (cf. mi355_bn_bwd_reduce_rows) */

@@ -555,7 +555,7 @@ extern "C" int mi355_bn_bwd_apply(const void* dy, int lddy, const void* y, int l
 // batch (the mapping of bn_act_pool2_kernel: a wave instruction covers 64 / tpr pixels two apart, the four together every byte of
 // two image-row segments), a workgroup pass rp windows = two image rows x 2 * rp pixels.  Geometry the host checks: tpr = C / EPC
 // a power of two, W a power-of-two multiple of 2 * rp.
-template <typename T> struct BnBwdPool2 {
+template <typename T, bool HASDY> struct BnBwdPool2 {
   static constexpr int EPC = 16 / (int)sizeof(T);
   const T* dy; int lddy; const T* dp; int lddp; const T* x; int ldx;
   const float* mean; const float* invstd; const float* mscale; const float* mshift;
@@ -575,7 +575,7 @@ template <typename T> struct BnBwdPool2 {
     for (int b = 0; b < 4; ++b) p.pix[b] = (size_t)(2 * R + (b >> 1)) * W + 2 * wcol + (b & 1);
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      p.gv[b] = keep ? ld16<T>(dy + p.pix[b] * lddy + c0) : ld16_nt<T>(dy + p.pix[b] * lddy + c0);
+      if constexpr (HASDY) p.gv[b] = keep ? ld16<T>(dy + p.pix[b] * lddy + c0) : ld16_nt<T>(dy + p.pix[b] * lddy + c0);
       p.xv[b] = keep ? ld16<T>(x + p.pix[b] * ldx + c0) : ld16_nt<T>(x + p.pix[b] * ldx + c0);
     }
     p.pv = keep ? ld16<T>(dp + ((size_t)R * (W >> 1) + wcol) * lddp + c0) : ld16_nt<T>(dp + ((size_t)R * (W >> 1) + wcol) * lddp + c0);
@@ -592,20 +592,21 @@ template <typename T> struct BnBwdPool2 {
     const bool win[4] = {w0, w1, w2, w3};
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      const float t = to_f32<T>(p.gv[b].v[e]) + (win[b] ? pg : 0.f);
+      // (HASDY == false: the pooling is the activation's ONLY consumer — VGG.py's feature stack —, its gradient is the routed dp alone)
+      const float t = (HASDY ? to_f32<T>(p.gv[b].v[e]) : 0.f) + (win[b] ? pg : 0.f);
       g[b] = a[b] > 0.f ? t : 0.f;
     }
   }
 };
 
-template <typename T> struct BnBwdReducePool2Op : BnBwdPool2<T> {
+template <typename T, bool HASDY> struct BnBwdReducePool2Op : BnBwdPool2<T, HASDY> {
   static constexpr int NQ = 2;
   static constexpr bool WRITES = false;
   static constexpr int BATCH_ROWS = 4;
   typedef float Acc;
   static constexpr int EPC = 16 / (int)sizeof(T);
   __device__ void load_cols(int c0) { this->load_common(c0); }
-  __device__ void finish(const typename BnBwdPool2<T>::Px& p, int, int, Acc (&acc)[NQ][EPC]) const {
+  __device__ void finish(const typename BnBwdPool2<T, HASDY>::Px& p, int, int, Acc (&acc)[NQ][EPC]) const {
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
       float g[4];
@@ -619,7 +620,7 @@ template <typename T> struct BnBwdReducePool2Op : BnBwdPool2<T> {
   }
 };
 
-template <typename T> struct BnBwdApplyPool2Op : BnBwdPool2<T> {
+template <typename T, bool HASDY> struct BnBwdApplyPool2Op : BnBwdPool2<T, HASDY> {
   static constexpr int NQ = 1;
   static constexpr bool WRITES = true;
   static constexpr int BATCH_ROWS = 4;
@@ -636,7 +637,7 @@ template <typename T> struct BnBwdApplyPool2Op : BnBwdPool2<T> {
       k1[e] = sums[C + c0 + e] * invM;
     }
   }
-  __device__ void finish(const typename BnBwdPool2<T>::Px& p, int, int c0, Acc (&acc)[NQ][EPC]) const {
+  __device__ void finish(const typename BnBwdPool2<T, HASDY>::Px& p, int, int c0, Acc (&acc)[NQ][EPC]) const {
     Vec16<T> o[4];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
@@ -663,7 +664,7 @@ static inline int exact_log2(long long v) {
   return l;
 }
 
-extern "C" int mi355_bn_bwd_reduce_pool2_rows(long long M) { return rowred_grid<BnBwdReducePool2Op<bf16_t>>(M); }
+extern "C" int mi355_bn_bwd_reduce_pool2_rows(long long M) { return rowred_grid<BnBwdReducePool2Op<bf16_t, true>>(M); }
 
 extern "C" int mi355_bn_bwd_pool2_ok(int H, int W, int C, int dtype) {
   const int epc = dtype_is_2byte(dtype) ? 8 : 4;
@@ -687,30 +688,34 @@ template <typename T, typename Op> static void fill_pool2(Op& op, const void* dy
 extern "C" int mi355_bn_bwd_reduce_pool2(const void* dy, int lddy, const void* dp, int lddp, const void* x, int ldx, const float* mean,
                                          const float* invstd, const float* mscale, const float* mshift, float* partial,
                                          int N, int H, int W, int C, int dtype, mi355_stream_t s) {
-  MI355_CHECK_ARG(dy && dp && x && mean && invstd && mscale && mshift && partial && N > 0, "bn_bwd_reduce_pool2: null pointer");
+  MI355_CHECK_ARG(dp && x && mean && invstd && mscale && mshift && partial && N > 0, "bn_bwd_reduce_pool2: null pointer");
   MI355_CHECK_ARG(mi355_bn_bwd_pool2_ok(H, W, C, dtype), "bn_bwd_reduce_pool2: %d x %d x %d is not a geometry of the window-ordered pass", H, W, C);
   return dispatch_dtype(dtype, "bn_bwd_reduce_pool2", [&](auto tag) {
     using T = decltype(tag);
-    BnBwdReducePool2Op<T> op;
-    fill_pool2<T>(op, dy, lddy, dp, lddp, x, ldx, mean, invstd, mscale, mshift, W, C);
-    op.keep = bn_reduce_keeps();
-    return rowred_launch<T>(op, (long long)N * H * W, C, partial, (hipStream_t)s);
+    auto run = [&](auto op) {
+      fill_pool2<T>(op, dy, lddy, dp, lddp, x, ldx, mean, invstd, mscale, mshift, W, C);
+      op.keep = bn_reduce_keeps();
+      return rowred_launch<T>(op, (long long)N * H * W, C, partial, (hipStream_t)s);
+    };
+    return dy ? run(BnBwdReducePool2Op<T, true>{}) : run(BnBwdReducePool2Op<T, false>{});
   });
 }
 
 extern "C" int mi355_bn_bwd_apply_pool2(const void* dy, int lddy, const void* dp, int lddp, const void* x, int ldx, const float* gamma,
                                         const float* mean, const float* invstd, const float* mscale, const float* mshift,
                                         const float* sums, void* dx, int lddx, int N, int H, int W, int C, int dtype, mi355_stream_t s) {
-  MI355_CHECK_ARG(dy && dp && x && gamma && mean && invstd && mscale && mshift && sums && dx && N > 0, "bn_bwd_apply_pool2: null pointer");
+  MI355_CHECK_ARG(dp && x && gamma && mean && invstd && mscale && mshift && sums && dx && N > 0, "bn_bwd_apply_pool2: null pointer");
   MI355_CHECK_ARG(mi355_bn_bwd_pool2_ok(H, W, C, dtype), "bn_bwd_apply_pool2: %d x %d x %d is not a geometry of the window-ordered pass", H, W, C);
   const long long M = (long long)N * H * W;
   return dispatch_dtype(dtype, "bn_bwd_apply_pool2", [&](auto tag) {
     using T = decltype(tag);
-    BnBwdApplyPool2Op<T> op;
-    fill_pool2<T>(op, dy, lddy, dp, lddp, x, ldx, mean, invstd, mscale, mshift, W, C);
-    op.keep = bn_apply_keeps();
-    op.gamma = gamma; op.sums = sums; op.dx = (T*)dx; op.lddx = lddx; op.invM = (float)(1.0 / (double)M); op.C = C;
-    return rowred_launch<T>(op, M, C, nullptr, (hipStream_t)s);
+    auto run = [&](auto op) {
+      fill_pool2<T>(op, dy, lddy, dp, lddp, x, ldx, mean, invstd, mscale, mshift, W, C);
+      op.keep = bn_apply_keeps();
+      op.gamma = gamma; op.sums = sums; op.dx = (T*)dx; op.lddx = lddx; op.invM = (float)(1.0 / (double)M); op.C = C;
+      return rowred_launch<T>(op, M, C, nullptr, (hipStream_t)s);
+    };
+    return dy ? run(BnBwdApplyPool2Op<T, true>{}) : run(BnBwdApplyPool2Op<T, false>{});
   });
 }
 

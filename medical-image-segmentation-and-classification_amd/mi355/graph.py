@@ -419,6 +419,14 @@ class Builder:
             root._written = True
         return 1 if was else 0
 
+    def grad_written(self, t):
+        """Has any backward launch emitted so far written (part of) the gradient of `t`?  (no side effect, unlike acc_flag)"""
+        g = t._grad
+        if g is None:
+            return False
+        root = g.parent if (not isinstance(g, V) and g.parent is not None) else g
+        return bool(g._written or root._written)
+
     def mark_full_written(self, t):
         g = self.grad_of(t)
         g._written = True
@@ -727,8 +735,10 @@ class Builder:
             return dy
         if pool_dp is not None:
             assert act and dres_to is None and post_to is None
-            self.bwd.append(Launch("mi355_bn_bwd_reduce_pool2", da, da.ld, pool_dp, pool_dp.ld, y, y.ld, st["mean"], st["invstd"],
-                                   st["scale"], st["shift"], part, y.N, y.H, y.W, C, self.code, nbytes=int(2.25 * y.M * C * self.esz)))
+            dal = da.ld if da is not None else 0          # (da None: the pooled gradient is the activation's whole gradient)
+            self.bwd.append(Launch("mi355_bn_bwd_reduce_pool2", da, dal, pool_dp, pool_dp.ld, y, y.ld, st["mean"], st["invstd"],
+                                   st["scale"], st["shift"], part, y.N, y.H, y.W, C, self.code,
+                                   nbytes=int((1.25 + (da is not None)) * y.M * C * self.esz)))
             sums = self.f32(2 * C)
             need_pg = bn.weight.requires_grad
             if need_pg:
@@ -740,9 +750,9 @@ class Builder:
             if bias is not None and bias.requires_grad and id(bias) not in self._grad_first:
                 self.pgrad(bias)
                 self.zero_grad_params.append(bias)
-            self.bwd.append(Launch("mi355_bn_bwd_apply_pool2", da, da.ld, pool_dp, pool_dp.ld, y, y.ld, bn.weight, st["mean"],
+            self.bwd.append(Launch("mi355_bn_bwd_apply_pool2", da, dal, pool_dp, pool_dp.ld, y, y.ld, bn.weight, st["mean"],
                                    st["invstd"], st["scale"], st["shift"], sums, dy, dy.ld, y.N, y.H, y.W, C, self.code,
-                                   nbytes=int(3.25 * y.M * C * self.esz)))
+                                   nbytes=int((2.25 + (da is not None)) * y.M * C * self.esz)))
             return dy
         # the ReLU mask is recomputed from the raw input with the forward's coefficients unless something was
         # added in front of the ReLU (residual / second operand), in which case the activated tensor is read
@@ -834,6 +844,8 @@ class Builder:
                 return
             if a._lazy_head is not None:      # logit_conv(): the gradient of `a` is dz[m] * w[c], recomputed inside the two passes
                 dy = self._bn_bwd(None, a, y, bn, st, act, bias=conv.bias, head=a._lazy_head)
+            elif a._lazy_pool is not None and not self.grad_written(a):      # the pooling was the only consumer: its routed gradient alone
+                dy = self._bn_bwd(None, a, y, bn, st, act, bias=conv.bias, pool_dp=a._lazy_pool)
             else:
                 da = self.grad_of(a)
                 # d(x + relu(.)) / dx = identity: folded into the BatchNorm apply pass
@@ -938,13 +950,15 @@ class Builder:
             if not y.needs_grad:
                 return
             dy = self.grad_of(y)
-            acc = self.acc_flag(x)
-            if (FUSE_POOL_BWD and acc and (k, s, p) == (2, 2, 0) and getattr(x, "_plain_bn_relu", False)
+            if (FUSE_POOL_BWD and (k, s, p) == (2, 2, 0) and getattr(x, "_plain_bn_relu", False)
                     and lib.mi355_bn_bwd_pool2_ok(x.H, x.W, x.C, self.code)):
-                # x = relu(bn(conv(.))) whose gradient already holds the other consumers' parts (they come later in the forward): the
-                # layer's two BatchNorm backward passes add the pooled gradient on the fly instead of a scatter pass over dx
+                # x = relu(bn(conv(.))): the layer's two BatchNorm backward passes add the pooled gradient on the fly instead of a
+                # scatter pass over dx — on top of the other consumers' parts (a U-Net's skip: they come later in the forward, so
+                # they are in dx by then), or ALONE when the pooling is the only consumer (VGG.py's feature stack): conv_bn_act's
+                # rule looks whether anything has been written
                 x._lazy_pool = dy
                 return
+            acc = self.acc_flag(x)
             xg = self.grad_of(x)
             self.bwd.append(Launch("mi355_maxpool_bwd", x, x.ld, dy, dy.ld, xg, xg.ld, x.N, x.H, x.W, x.C, k, s, p, acc, self.code))
         self.rule(rule)

@@ -191,6 +191,47 @@ def test_bn_act_with_fused_maxpool_is_bit_identical_to_the_two_passes(dtype, act
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(3, 64, 8, 64), (2, 128, 6, 32)])
+def test_bn_backward_when_the_pooling_is_the_only_consumer(shape, dtype):
+    """dy = NULL in mi355_bn_bwd_reduce_pool2 / _apply_pool2: the activation feeds the MaxPool2d(2, 2) ONLY (VGG.py's feature
+    stack), so its gradient is the routed dp alone — against mi355_maxpool_bwd (overwriting) + the row-ordered passes."""
+    n, c, h, w = shape
+    code = DTYPE_CODE[dtype]
+    if not lib.mi355_bn_bwd_pool2_ok(h, w, c, code):
+        pytest.skip("row too short for this channel count")
+    g = torch.Generator().manual_seed(c)
+    m = n * h * w
+    x = q(torch.round(torch.randn(n, c, h, w, generator=g) * 2) / 2, dtype)
+    dp = q(torch.randn(n, c, h // 2, w // 2, generator=g), dtype)
+    gamma = torch.rand(c, generator=g) + 0.5
+    mean = x.float().mean((0, 2, 3)); invstd = (x.float().var((0, 2, 3), unbiased=False) + 1e-5).rsqrt()
+    beta = torch.randn(c, generator=g) * 0.3
+    D = [dev(t.float().contiguous()) for t in (gamma, mean, invstd, gamma * invstd, beta - mean * gamma * invstd)]
+    xd, dpd = to_nhwc(x, dtype), to_nhwc(dp, dtype)
+    res = []
+    for fused in (0, 1):
+        dx = torch.zeros(n, h, w, c, dtype=dtype, device=DEV)
+        nb, part = _partials(m, c)
+        sums = torch.empty(2 * c, device=DEV); dg = torch.empty(c, device=DEV); db = torch.empty(c, device=DEV)
+        if fused:
+            lib.mi355_bn_bwd_reduce_pool2(None, 0, dpd, c, xd, c, D[1], D[2], D[3], D[4], part, n, h, w, c, code)
+            lib.mi355_bn_bwd_finalize(part, min(nb, lib.mi355_bn_bwd_reduce_pool2_rows(m)), c, sums, dg, db, 0.0)
+            lib.mi355_bn_bwd_apply_pool2(None, 0, dpd, c, xd, c, D[0], D[1], D[2], D[3], D[4], sums, dx, c, n, h, w, c, code)
+        else:
+            a = torch.empty(n, h, w, c, dtype=dtype, device=DEV); da = torch.full_like(a, float("nan"))
+            lib.mi355_bn_act(xd, c, D[3], D[4], None, 0, None, None, None, 0, a, c, m, c, 1, code)
+            lib.mi355_maxpool_bwd(a, c, dpd, c, da, c, n, h, w, c, 2, 2, 0, 0, code)
+            lib.mi355_bn_bwd_reduce(da, c, None, 0, xd, c, D[1], D[2], D[3], D[4], part, m, c, 1, code)
+            lib.mi355_bn_bwd_finalize(part, min(nb, lib.mi355_bn_bwd_reduce_rows(m)), c, sums, dg, db, 0.0)
+            lib.mi355_bn_bwd_apply(da, c, None, 0, xd, c, D[0], D[1], D[2], D[3], D[4], sums, dx, c, None, 0, None, 0, 0, None, m, c, 1, code)
+        torch.cuda.synchronize()
+        res.append((dx.float().cpu(), sums.cpu(), dg.cpu(), db.cpu()))
+    tol = 1e-5 if dtype == torch.float32 else TOL[dtype]
+    for i in range(4):
+        assert rel_err(res[1][i], res[0][i]) < (tol if i else 2 * tol), i
+
+
+@pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("shape", [(3, 64, 8, 64), (2, 128, 6, 32), (2, 256, 4, 32), (1, 32, 4, 256)])
 def test_bn_backward_with_lazy_maxpool_gradient(shape, dtype):
     """mi355_bn_bwd_reduce_pool2 / _apply_pool2 (the gradient of the MaxPool2d(2, 2) of AttentionUNet.py:61,89-95 added inside the

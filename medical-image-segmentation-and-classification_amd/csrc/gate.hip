@@ -472,6 +472,50 @@ __global__ __launch_bounds__(256) void gate_mul_bwd_kernel(const T* __restrict__
   const long long r0 = (long long)blockIdx.x * rows_per_block;
   const long long r1 = min(M, r0 + rows_per_block);
   double s0 = 0, s1 = 0;
+  if (cp <= tpr) {
+    // one chunk per lane (C <= 512 in the 2-byte types): U row groups in flight, unconditional loads from a clamped (row, chunk) —
+    // a guarded load is waited for before the next is issued (gate_psi_fwd_kernel) —, lanes past the last chunk write nothing
+    constexpr int U = 4;
+    const bool on = sub < cp;
+    const int cb = (on ? sub : 0) * EPC;
+    for (long long base = r0 + wave * rpw; base < r1; base += (long long)U * 4 * rpw) {
+      Vec16<T> gv[U], xv[U], ov[U];
+      float zz[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long r = base + (long long)u * 4 * rpw + rsub;
+        const size_t rc = (size_t)(r < r1 ? r : r1 - 1);
+        gv[u] = ld16<T>(dy + rc * lddy + cb);
+        xv[u] = ld16<T>(x + rc * ldx + cb);
+        if (accumulate) ov[u] = ld16_plain<T>(dx + rc * lddx + cb);
+        zz[u] = z[rc];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long r = base + (long long)u * 4 * rpw + rsub;
+        const float psi = 1.f / (1.f + __expf(-(zz[u] * sc + sh)));
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          const float gg = to_f32<T>(gv[u].v[e]);
+          acc += gg * to_f32<T>(xv[u].v[e]);
+          const float d = gg * psi;
+          ov[u].v[e] = from_f32<T>(accumulate ? to_f32<T>(ov[u].v[e]) + d : d);
+        }
+        if (!on) acc = 0.f;
+        if (r < r1 && on) st16<T>(dx + (size_t)r * lddx + cb, ov[u]);
+        acc = seg_sum(acc, tpr);
+        if (r < r1 && sub == 0) {
+          const float d = acc * psi * (1.f - psi);
+          dzn[r] = d;
+          s0 += d;
+          s1 += (double)d * ((zz[u] - mu) * is);
+        }
+      }
+    }
+    block_pair_sum(s0, s1, partial);
+    return;
+  }
   for (long long base = r0 + wave * rpw; base < r1; base += 4 * rpw) {
     const long long r = base + rsub;
     float acc = 0.f, psi = 0.f, zz = 0.f;

@@ -26,6 +26,10 @@ for M, C in ((2097152, 32), (524288, 64), (131072, 128), (32768, 256)):
         "gate_bn_bwd_apply": (lambda: lib.mi355_gate_bn_bwd_apply(dz, g1, C, x1, C, *co, w, co[0], co[4], sums[0], sums[1], dg, C, dx, C, M, C, code),
                               4 * M * C * es + 4 * M),
     }
+    Cx = 2 * C         # the gated skip tensor has twice the gate's inner channels
+    xs = torch.randn(M, Cx, device=dev).to(dt); dys = torch.randn(M, Cx, device=dev).to(dt); dxs = torch.empty(M, Cx, device=dev, dtype=dt)
+    dzn = torch.empty(M, device=dev); p2 = torch.empty(nb * 2, device=dev); one = torch.ones(1, device=dev); zero = torch.zeros(1, device=dev)
+    runs["gate_mul_bwd"] = (lambda: lib.mi355_gate_mul_bwd(dys, Cx, xs, Cx, z, one, zero, zero, one, dxs, Cx, 0, dzn, p2, M, Cx, code), 3 * M * Cx * es)
     if C == 64:        # the logit head's one-channel convolution (AttentionUNet.py:84) at the full resolution
         Mh = 2097152
         xh = torch.randn(Mh, C, device=dev).to(dt); zh = torch.empty(Mh, device=dev)

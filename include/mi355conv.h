@@ -118,6 +118,10 @@ int mi355_conv2d_igemm_stat_rows(int N, int Hi, int Wi, int Ci, int Ho, int Wo, 
  * [Co][Ci_real][KH][KW] (or [Ci_real][Co][KH][KW] when transposed), beta in {0,1}.
  * (convolution_backward weight grad, utils/helpers.py:329.) */
 int mi355_conv2d_wgrad_splits(int N, int Ho, int Wo, int Ci, int Co, int KH, int KW);
+/* The kernel mi355_conv2d_wgrad runs for a 2-byte layer of this geometry: 0 = the generic per-tap split-K kernel; nine-tap kernels
+ * (3x3 / stride 1 / pad 1, Ho % 8 == 0): 1 = four waves, rows of 32-pixel segments; 2 = four waves, 16-pixel-wide images two at a
+ * time; 3 = eight waves, rows of 64-pixel segments (wgrad3x3_halo8_kernel); 4 = eight waves, 32-pixel-wide images two at a time. */
+int mi355_conv2d_wgrad_variant(int N, int Ho, int Wo, int KH, int KW, int stride, int pad, int dtype);
 int mi355_conv2d_wgrad(const void* x, const void* dy, float* ws, int splits,
                        int N, int Hi, int Wi, int Ci, int ldx,
                        int Ho, int Wo, int Co, int ldy,

@@ -12,6 +12,7 @@
 #include "common.hpp"
 #include "dma.hpp"
 #include "wgrad3x3_halo.hpp"
+#include "wgrad3x3_halo8.hpp"
 #include <stdlib.h>
 
 struct WgradArgs {
@@ -218,25 +219,44 @@ static void wgrad_tiles(int Co, int Ci, int& bco, int& bci) {
   bci = (Ci % 128 == 0) ? 128 : 64;
 }
 
-// nine-tap kernel: 0 = not served, 1 = rows of 32-pixel segments, 2 = 16-pixel-wide images taken two at a time
+// nine-tap kernels: 0 = not served; four-wave kernel (wgrad3x3_halo.hpp): 1 = rows of 32-pixel segments, 2 = 16-pixel-wide
+// images taken two at a time; eight-wave kernel (wgrad3x3_halo8.hpp): 3 = rows of 64-pixel segments, 4 = 32-pixel-wide images
+// taken two at a time.  MI355_WGRAD8=0 keeps every shape on the four-wave kernel (A/B switch).
 static int halo_wgrad_mode(int N, int Ho, int Wo, int KH, int KW) {
+  static const int use8 = getenv("MI355_WGRAD8") ? atoi(getenv("MI355_WGRAD8")) : 1;
   if (KH != 3 || KW != 3 || Ho % 8 != 0) return 0;
+  if (use8 && Wo % 64 == 0) return 3;
+  if (use8 && Wo == 32 && N % 2 == 0) return 4;
   if (Wo % 32 == 0) return 1;
   if (Wo == 16 && N % 2 == 0) return 2;
   return 0;
+}
+// work items of one (x, dy) pair: (image or image pair) x row segment x row band
+static int halo_wgrad_items(int mode, int N, int Ho, int Wo, int rb) {
+  switch (mode) {
+    case 1: return N * (Wo / 32) * (Ho / rb);
+    case 3: return N * (Wo / 64) * (Ho / rb);
+    default: return (N / 2) * (Ho / rb);             // 2, 4: image pairs
+  }
 }
 
 extern "C" int mi355_conv2d_wgrad_splits(int N, int Ho, int Wo, int Ci, int Co, int KH, int KW) {
   if (const int mode = halo_wgrad_mode(N, Ho, Wo, KH, KW)) {      // nine-tap kernel: 64x64 tiles, work items = 32-pixel-wide row bands
     const int rb = Ho % 32 == 0 ? 32 : (Ho % 16 == 0 ? 16 : 8);
-    const long long items = mode == 2 ? (long long)(N / 2) * (Ho / rb) : (long long)N * (Wo / 32) * (Ho / rb);
+    const long long items = halo_wgrad_items(mode, N, Ho, Wo, rb);
     const long long tiles = (long long)ceil_div(Co, 64) * ceil_div(Ci, 64);
-    // ONE workgroup per CU.  Two are resident (254 VGPRs) and run the kernel 18 % faster on its own (3.4 vs 4.0 ms per
-    // Attention U-Net step), but the kernel lives on the side stream next to the data-gradient chain: at one per CU it leaves
+    // Four-wave kernel: ONE workgroup per CU.  Two are resident (254 VGPRs) and run the kernel 18 % faster on its own (3.4 vs 4.0 ms
+    // per Attention U-Net step), but the kernel lives on the side stream next to the data-gradient chain: at one per CU it leaves
     // half of every SIMD's registers to the main stream's kernels, the two interleave instead of queueing, and half as many
     // partial slabs reach the reduce.  Step: 512 / 384 / 320 / 256 / 192 / 128 workgroups = 18.53 / 18.58 / 18.47 / 18.18 /
-    // 18.28 / 19.28 ms.
-    static const int wgs = getenv("MI355_WGRAD_WGS") ? atoi(getenv("MI355_WGRAD_WGS")) : 256;      // (A/B switch)
+    // 18.28 / 19.28 ms (round 2).
+    // Eight-wave kernel: a workgroup OWNS its CU (512 threads x 256 registers, 115 KB of LDS), so its grid is a share of the chip
+    // handed to the side stream for the length of the launch: on 128 CUs the weight gradients run at twice the per-CU rate of the
+    // four-wave kernel while the other 128 CUs belong to the main stream's data-gradient / BatchNorm chain alone, and half as many
+    // partial slabs are written and reduced.  Step: 64 / 96 / 112 / 128 / 144 / 160 / 192 / 256 workgroups = 17.7 / 16.2 / 16.1 /
+    // 15.40 / 15.6 / 15.65 / 15.9 / 16.3 ms against 15.74 for the four-wave kernel (profiles/r04a_wgs_sweep8.txt).
+    static const int wgs_env = getenv("MI355_WGRAD_WGS") ? atoi(getenv("MI355_WGRAD_WGS")) : 0;      // (A/B switch)
+    const int wgs = wgs_env > 0 ? wgs_env : (mode >= 3 ? 128 : 256);
     long long s = wgs / tiles;
     if (s > items) s = items;
     const long long slab = (long long)Co * 9 * Ci * 4;
@@ -284,9 +304,25 @@ static int launch_wgrad3x3(const Wgrad3Args& h, dim3 grid, hipStream_t s) {
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }
+template <typename T, bool W32>
+static int launch_wgrad3x3_8(const Wgrad3Args& h, dim3 grid, hipStream_t s) {
+  constexpr int lds_bytes = Wgrad8Lds::BYTES;
+  static const hipError_t configured =
+      hipFuncSetAttribute((const void*)wgrad3x3_halo8_kernel<T, W32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (configured != hipSuccess)
+    MI355_FAIL((int)configured, "wgrad3x3_halo8: cannot reserve %d B of LDS: %s", lds_bytes, hipGetErrorString(configured));
+  hipLaunchKernelGGL((wgrad3x3_halo8_kernel<T, W32>), grid, dim3(512), lds_bytes, s, h);
+  MI355_LAUNCH_CHECK();
+  return MI355_OK;
+}
 static int launch_wgrad3x3_any(const Wgrad3Args& h, dim3 grid, int hmode, int dtype, hipStream_t s) {
-  if (hmode == 2) return dtype == MI355_F16 ? launch_wgrad3x3<f16_t, true>(h, grid, s) : launch_wgrad3x3<bf16_t, true>(h, grid, s);
-  return dtype == MI355_F16 ? launch_wgrad3x3<f16_t, false>(h, grid, s) : launch_wgrad3x3<bf16_t, false>(h, grid, s);
+  const bool f16 = dtype == MI355_F16;
+  switch (hmode) {
+    case 2: return f16 ? launch_wgrad3x3<f16_t, true>(h, grid, s) : launch_wgrad3x3<bf16_t, true>(h, grid, s);
+    case 3: return f16 ? launch_wgrad3x3_8<f16_t, false>(h, grid, s) : launch_wgrad3x3_8<bf16_t, false>(h, grid, s);
+    case 4: return f16 ? launch_wgrad3x3_8<f16_t, true>(h, grid, s) : launch_wgrad3x3_8<bf16_t, true>(h, grid, s);
+    default: return f16 ? launch_wgrad3x3<f16_t, false>(h, grid, s) : launch_wgrad3x3<bf16_t, false>(h, grid, s);
+  }
 }
 
 extern "C" int mi355_conv2d_wgrad(const void* x, const void* dy, float* ws, int splits, int N, int Hi, int Wi, int Ci,
@@ -314,7 +350,7 @@ extern "C" int mi355_conv2d_wgrad(const void* x, const void* dy, float* ws, int 
   const int hmode = halo_wgrad_mode(N, Ho, Wo, KH, KW);
   // (the nine-tap kernel addresses an image — two in the 16-pixel mode — through buffer descriptors with 32-bit lane and row
   //  offsets: 2 GiB or more per image goes to the generic kernel, which carries 64-bit addresses)
-  const long long img_lim = (1ll << 31) / (hmode == 2 ? 2 : 1);
+  const long long img_lim = (1ll << 31) / (hmode == 2 || hmode == 4 ? 2 : 1);
   const bool fits = (long long)Hi * Wi * ldx * esz < img_lim && (long long)Ho * Wo * ldy * esz < img_lim;
   if (dtype_is_2byte(dtype) && use_halo && stride == 1 && pad == 1 && hmode && Ho == a.Hlog && Wo == a.Wlog && fits) {
     Wgrad3Args h;
@@ -323,13 +359,19 @@ extern "C" int mi355_conv2d_wgrad(const void* x, const void* dy, float* ws, int 
     h.N = N; h.Hi = Hi; h.Wi = Wi; h.Ci = Ci; h.ldx = ldx;
     h.H = Ho; h.W = Wo; h.Co = Co; h.ldy = ldy; h.up = up ? 1 : 0;
     h.RB = Ho % 32 == 0 ? 32 : (Ho % 16 == 0 ? 16 : 8);
-    h.items = hmode == 2 ? (N / 2) * (Ho / h.RB) : N * (Wo / 32) * (Ho / h.RB);
+    h.items = halo_wgrad_items(hmode, N, Ho, Wo, h.RB);
     h.items_per_app = h.items;
     h.items_per_block = ceil_div(h.items, splits);
     dim3 grid(ceil_div(Co, 64) * ceil_div(Ci, 64), splits);
     return launch_wgrad3x3_any(h, grid, hmode, dtype, (hipStream_t)s);
   }
   return dispatch_dtype(dtype, "conv2d_wgrad", [&](auto tag) { return wgrad_launch<decltype(tag)>(a, splits, (hipStream_t)s); });
+}
+
+extern "C" int mi355_conv2d_wgrad_variant(int N, int Ho, int Wo, int KH, int KW, int stride, int pad, int dtype) {
+  static const int use_halo = getenv("MI355_WGRAD_HALO") ? atoi(getenv("MI355_WGRAD_HALO")) : 1;
+  if (!use_halo || !dtype_is_2byte(dtype) || stride != 1 || pad != 1) return 0;
+  return halo_wgrad_mode(N, Ho, Wo, KH, KW);
 }
 
 extern "C" int mi355_conv2d_wgrad_multi_ok(int N, int Ho, int Wo, int dtype) {
@@ -361,7 +403,7 @@ extern "C" int mi355_conv2d_wgrad_multi(const void* x0, const void* dy0, const v
   h.N = N; h.Hi = Hi; h.Wi = Wi; h.Ci = Ci; h.ldx = ldx;
   h.H = Ho; h.W = Wo; h.Co = Co; h.ldy = ldy; h.up = up ? 1 : 0;
   h.RB = Ho % 32 == 0 ? 32 : (Ho % 16 == 0 ? 16 : 8);
-  h.items_per_app = hmode == 2 ? (N / 2) * (Ho / h.RB) : N * (Wo / 32) * (Ho / h.RB);
+  h.items_per_app = halo_wgrad_items(hmode, N, Ho, Wo, h.RB);
   h.items = napp * h.items_per_app;
   MI355_CHECK_ARG(splits <= h.items, "conv2d_wgrad_multi: more splits (%d) than work items (%d)", splits, h.items);
   h.items_per_block = ceil_div(h.items, splits);

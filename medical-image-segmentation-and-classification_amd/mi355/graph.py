@@ -590,7 +590,7 @@ class Builder:
                 ws = self.ws_bytes(splits * Co * k * k * x.C * 4)
                 self.bwd.append(Launch("mi355_conv2d_wgrad", x, dy, ws, splits, x.N, x.H, x.W, x.C, x.ld, Ho, Wo, Co, dy.ld,
                                        k, k, s, p, 1 if up else 0, self.code, flops=flops, nbytes=nbytes, side=True,
-                                       tag=self.wgrad_tag(Co, x.C, k, s, Ho, Wo)))
+                                       tag=self.wgrad_tag(Co, x.C, k, s, Ho, Wo, x.N, p)))
                 ref, beta = self.pgrad(conv.weight)
                 self.bwd.append(Launch("mi355_conv2d_wgrad_reduce", ws, splits, ref, Co, x.C, conv.in_channels, k, k, 0, beta, side=True))
             if conv.bias is not None and conv.bias.requires_grad and not bias_done:
@@ -629,7 +629,7 @@ class Builder:
             ops += list(pend[i]) if i < n else [None, None]
         self.bwd.append(Launch("mi355_conv2d_wgrad_multi", *ops, n, ws, splits, x0.N, x0.H, x0.W, x0.C, x0.ld, Ho, Wo, Co,
                                pend[0][1].ld, 1 if up else 0, self.code, flops=flops * n, nbytes=nbytes * n, side=True,
-                               tag=self.wgrad_tag(Co, x0.C, k, 1, Ho, Wo)))
+                               tag=self.wgrad_tag(Co, x0.C, k, 1, Ho, Wo, x0.N, 1)))
         ref, beta = self.pgrad(conv.weight)
         self.bwd.append(Launch("mi355_conv2d_wgrad_reduce", ws, splits, ref, Co, x0.C, conv.in_channels, k, k, 0, beta, side=True))
 
@@ -651,11 +651,12 @@ class Builder:
         return {2: "conv3x3_halo_rw_kernel<8,32>", 3: "conv3x3_halo_rw_kernel<16,16>", 4: f"conv1x1_stream_kernel<{ci},{co}>",
                 5: "conv3x3_halo_pp_kernel", 6: "conv3x3_halo_pp128_kernel", 7: "conv3x3_ws_kernel<64,8>", 8: "conv3x3_ws_kernel<128,4>"}[v]
 
-    def wgrad_tag(self, co, ci, k=1, s=1, Ho=0, Wo=0):
+    def wgrad_tag(self, co, ci, k=1, s=1, Ho=0, Wo=0, N=0, p=None):
+        """Name of the kernel mi355_conv2d_wgrad runs: the launcher's own choice (mi355_conv2d_wgrad_variant)."""
         t = "f32" if self.dtype == torch.float32 else "bf16"       # (the fp16 build runs the same variants as bf16)
-        halo = os.environ.get("MI355_WGRAD_HALO", "1") != "0"                                      # A/B switch of the launcher
-        if halo and t == "bf16" and k == 3 and s == 1 and Ho % 8 == 0 and (Wo % 32 == 0 or Wo == 16):      # (Wo == 16: even batches)
-            return "wgrad3x3_halo_kernel"
+        v = lib.mi355_conv2d_wgrad_variant(N, Ho, Wo, k, k, s, (k // 2) if p is None else p, self.code) if t == "bf16" else 0
+        if v:
+            return "wgrad3x3_halo8_kernel" if v >= 3 else "wgrad3x3_halo_kernel"
         return f"conv_wgrad_kernel<{t},{128 if co % 128 == 0 else 64},{128 if ci % 128 == 0 else 64}>"
 
     def bias_grad_from(self, dy, bias):

@@ -69,6 +69,8 @@ for k in sorted(fetch, key=lambda k: -(2 * fetch[k] + write.get(k, 0))):
     tag = tag.replace("<bf16>", "").replace("<f16>", "")
     if tag.startswith("wgrad3x3_halo_kernel"):      # (both W16 instantiations of the nine-tap weight gradient: one bench tag)
         tag = "wgrad3x3_halo_kernel"
+    if tag.startswith("wgrad3x3_halo8_kernel"):     # (... and both W32 instantiations of its eight-wave form)
+        tag = "wgrad3x3_halo8_kernel"
     e = {"launches_profiled": nf[k], "fetch_MB_per_launch": round(f, 1), "write_MB_per_launch": round(w, 1),
          "hbm_MB_per_launch": round(f + w, 1)}
     if tag in out["kernels"]:                      # two instantiations under one bench tag: launch-weighted mean

@@ -176,6 +176,15 @@ WG_CASES = [  # N, Ci, H, W, Co, K, stride, pad, up
     (2, 128, 8, 16, 64, 3, 1, 1, 1),
     (1, 192, 40, 32, 128, 3, 1, 1, 0),
     (3, 64, 32, 96, 64, 3, 1, 1, 0),
+    # eight-wave nine-tap kernel (wgrad3x3_halo8.hpp): rows of 64-pixel segments — two segments per row and a 32-row band, several
+    # channel tiles, two bands per image, fused up-sampling — and 32-pixel-wide images two at a time: 8-row bands with a channel
+    # tail, fused up-sampling (Wi = 16)
+    (2, 64, 32, 128, 64, 3, 1, 1, 0),
+    (1, 128, 16, 64, 192, 3, 1, 1, 0),
+    (1, 64, 64, 64, 64, 3, 1, 1, 0),
+    (2, 64, 16, 32, 64, 3, 1, 1, 1),
+    (4, 96, 24, 32, 64, 3, 1, 1, 0),
+    (4, 64, 8, 16, 128, 3, 1, 1, 1),
 ]
 
 
@@ -417,6 +426,17 @@ def test_weight_stationary_variant_dispatch():
     assert lib.mi355_conv2d_igemm_variant_n(2, 64, 64, 64, 64, 64, 64, 3, 3, 1, 1, -1, 1, 0, code) == 2           # 32 tiles: too few
     assert lib.mi355_conv2d_igemm_stat_rows(32, 256, 256, 64, 256, 256, 64, 3, 3, 1, 1, -1, 1, 0, code) == 512           # of 8192 tiles
     assert lib.mi355_conv2d_igemm_variant_n(2, 64, 64, 64, 64, 64, 64, 3, 3, 1, 1, -1, 1, 0, DTYPE_CODE[torch.float32]) == 0
+
+
+def test_weight_gradient_variant_dispatch():
+    """mi355_conv2d_wgrad_variant reports the launcher's choice: the eight-wave nine-tap kernel for rows of 64-pixel segments and for
+    32-pixel-wide images in pairs, the four-wave kernel for the other 32-pixel-segment shapes and 16-pixel-wide pairs, the generic
+    split-K kernel for everything else (fp32, strides, odd shapes)."""
+    code = DTYPE_CODE[torch.bfloat16]
+    v = lambda n, h, w, k=3, s=1, p=1, c=code: lib.mi355_conv2d_wgrad_variant(n, h, w, k, k, s, p, c)
+    assert v(32, 256, 256) == 3 and v(32, 64, 64) == 3 and v(32, 32, 32) == 4 and v(32, 16, 16) == 2
+    assert v(3, 32, 32) == 1 and v(2, 32, 96) == 1 and v(3, 16, 16) == 0 and v(2, 12, 12) == 0
+    assert v(2, 64, 64, 1, 1, 0) == 0 and v(2, 64, 64, 3, 2, 1) == 0 and v(2, 64, 64, c=DTYPE_CODE[torch.float32]) == 0
 
 
 def test_counted_vmcnt_matches_drained_build(tmp_path):

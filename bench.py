@@ -60,6 +60,38 @@ def make_batch(b, hw, seed, device):
 SPLIT_BY_SHAPE = False
 
 
+def dp_child_command(argv, gpus, port):
+    """The command `bench.py --gpus N` runs when it was started WITHOUT a launcher (no WORLD_SIZE in the environment): one rank
+    per GPU of this node under torch.distributed.run, the same arguments passed through."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(argv, gpus):
+    """`python bench.py --gpus N` with N > 1 and no launcher: start the N ranks as a CHILD process (never exec: this process has
+    imported torch; and never fall through to a one-GPU run labelled as N), relay rank 0's JSON line, exit with the child's code."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()                 # (counting devices does not initialise the runtime)
+    if have < gpus:
+        raise SystemExit(f"bench.py --gpus {gpus}: this node shows {have} GPU(s); refusing to report a smaller run under that label")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(dp_child_command(argv, gpus, port), stdout=subprocess.PIPE, env=env, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        sys.stderr.write(r.stdout)
+        raise SystemExit(r.returncode or f"bench.py --gpus {gpus}: the {gpus}-rank child printed no result line")
+    res = json.loads(lines[-1])
+    if res.get("n_gpus") != gpus:
+        raise SystemExit(f"bench.py --gpus {gpus}: the child reported n_gpus={res.get('n_gpus')}")
+    print(lines[-1], flush=True)
+    raise SystemExit(0)
+
+
 def profile_plan(plan, x, stream, reps=2):
     """Instrumented replay: HIP events around every launch of the forward and backward plans."""
     # single-stream resolution on purpose: HIP events on this stream must bracket every kernel (the production
@@ -196,13 +228,15 @@ def main():
     args = ap.parse_args()
     if args.serial_streams:
         os.environ["MI355_SIDE_STREAM"] = "0"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(sys.argv[1:], args.gpus)          # (does not return)
 
     t_start = time.perf_counter()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the result line would be mislabelled")
     # stdout carries exactly ONE line (the JSON, rank 0): libraries that print banners to fd 1 (RCCL prints "Hostname : ..." /
     # "Librccl path : ..." when the communicator is created) are pointed at stderr for the rest of the run
     sys.stdout.flush()

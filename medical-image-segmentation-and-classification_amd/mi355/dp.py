@@ -55,8 +55,13 @@ class DataParallel:
         mi355/__init__.py asks for eight — which only takes effect if the runtime had not initialised yet."""
         import mi355
         if torch.cuda.is_available() and not mi355.HW_QUEUES_IN_TIME:
-            raise RuntimeError("mi355.dp: the HIP runtime was initialised before `mi355` was imported, so GPU_MAX_HW_QUEUES=8 could "
-                               "not be applied; import the package (or export GPU_MAX_HW_QUEUES yourself) before the first CUDA call")
+            msg = ("mi355.dp: the HIP runtime was initialised before `mi355` was imported, so GPU_MAX_HW_QUEUES=8 could not be "
+                   "applied: the main, weight-gradient and all-reduce streams may share a hardware queue (+0.7 ms on a 19 ms step); "
+                   "import the package, or export GPU_MAX_HW_QUEUES=8, before the first CUDA call (INTEGRATION.md)")
+            if os.environ.get("MI355_DP_STRICT_QUEUES") == "1":
+                raise RuntimeError(msg)
+            import warnings
+            warnings.warn(msg, RuntimeWarning, stacklevel=3)
 
     def _init_native(self):
         """One RCCL communicator per process through the C ABI; rank 0's 128-byte id travels over the torch.distributed group
@@ -87,6 +92,14 @@ class DataParallel:
         replicas that sum gradients but apply them to different weights."""
         self.engine._check_storage()
         dist.broadcast(self.engine.flat_p, src=src, group=self.group)
+        self.engine.invalidate_packs()         # (a broadcast does not bump version counters: frozen-weight packs would go stale)
+        self.sync_buffers(src)
+
+    @torch.no_grad()
+    def sync_buffers(self, src: int = 0):
+        """Rank ``src``'s buffers (BatchNorm running statistics) on every rank: what DistributedDataParallel's per-forward buffer
+        broadcast leaves in the model.  helpers.train() calls it once per epoch, in front of the validation pass, so every rank
+        validates — and rank 0 checkpoints — the same model."""
         by_dtype = {}
         for b in self.net.buffers():
             by_dtype.setdefault(b.dtype, []).append(b)

@@ -51,6 +51,7 @@ class Engine:
         self._drop_seed = 0x5EED
         self.grad_hooks = []            # callables(plan) run after the backward launches (data parallel)
         self.bwd_runner = None          # optional replacement for plan.run_backward (overlapped all-reduce)
+        self.pack_epoch = 0             # bumped by invalidate_packs(): frozen-weight packs are rebuilt on the next forward
 
     # ---- flat parameter / gradient storage -----------------------------------------------------------
     def flatten(self):
@@ -85,6 +86,11 @@ class Engine:
             if p.data_ptr() != base + self.offsets[id(p)][0] * 4 or p.device != self.flat_p.device:
                 self.flatten()          # .to(device) / .cuda() re-created the parameter storage
                 return
+
+    def invalidate_packs(self):
+        """Parameters were written behind autograd's version counters (a broadcast into the flat buffer, ``p.data`` edits, raw
+        pointers): every plan re-packs its FROZEN weights on its next forward (trainable ones are re-packed every step anyway)."""
+        self.pack_epoch += 1
 
     def grad_ref(self, p):
         o, _ = self.offsets[id(p)]

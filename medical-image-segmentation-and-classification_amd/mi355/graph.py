@@ -131,6 +131,7 @@ class Plan:
         self.pre, self.fwd, self.bwd = b.pre, b.fwd, b.bwd
         self.static_pack, self.static_params, self._static_sig = b.static_pack, b.static_params, None
         self.flat_p = b.engine.flat_p
+        self.engine = b.engine            # (its pack_epoch is part of the frozen packs' signature)
         self.keep = b.keep
         self.acts = b.acts                # [(kind, handles...)] in forward order: activations at the network's kinks (tests / diagnostics)
         self.input = b.input
@@ -247,11 +248,13 @@ class Plan:
                 raise RuntimeError(f"{name} failed (rc={rc}): {lib.raw('mi355_last_error')().decode()}")
 
     def refresh_static_packs(self, stream):
-        """Weight packs of frozen parameters: one launch when they changed (load_state_dict / in-place edits bump the
-        parameters' version counters, a data-parallel state sync the flat buffer's), nothing otherwise."""
+        """Weight packs of frozen parameters: one launch when they changed, nothing otherwise.  load_state_dict / in-place edits
+        bump the parameters' version counters; writers that version counters do not see — a collective into the flat buffer
+        (DataParallel.sync_state: dist.broadcast leaves ``_version`` alone), ``p.data`` edits, raw-pointer writes — call
+        ``Engine.invalidate_packs()``, whose epoch is the third part of the signature."""
         if self.static_pack is None:
             return
-        sig = (self.flat_p._version, sum(p._version for p in self.static_params))
+        sig = (self.flat_p._version, sum(p._version for p in self.static_params), self.engine.pack_epoch)
         if sig != self._static_sig:
             self._run(self._resolve([self.static_pack], stream))
             self._static_sig = sig
@@ -423,7 +426,10 @@ class Builder:
         """Has any backward launch emitted so far written (part of) the gradient of `t`?  (no side effect, unlike acc_flag)"""
         g = t._grad
         if g is None:
-            return False
+            # a slice of a wider buffer (concat input) whose consumer wrote the PARENT's gradient through grad_of(parent): the
+            # slice has no handle of its own yet, but its gradient exists
+            parent = None if isinstance(t, V) else t.parent
+            return bool(parent is not None and parent._grad is not None and parent._grad._written)
         root = g.parent if (not isinstance(g, V) and g.parent is not None) else g
         return bool(g._written or root._written)
 
@@ -600,7 +606,9 @@ class Builder:
                     acc = self.acc_flag(x)
                     xg = self.grad_of(x)
                     tag = self.igemm_tag(x.N, Ho, Wo, Co, 2 * x.H, 2 * x.W, x.C, k, 1, -1, p, s, 0)
-                    if lib.mi355_conv2d_igemm_variant(Ho, Wo, Co, 2 * x.H, 2 * x.W, x.C, k, k, 1, -1, p, s, 0, self.code) in (2, 3, 5, 6, 7, 8):
+                    # (the launcher's own choice for THIS batch: the shape-level variant may fall back, by batch size, to the LDS-DMA ring
+                    #  kernel, which has no 2x2-sum epilogue)
+                    if lib.mi355_conv2d_igemm_variant_n(x.N, Ho, Wo, Co, 2 * x.H, 2 * x.W, x.C, k, k, 1, -1, p, s, 0, self.code) in (2, 3, 5, 6, 7, 8):
                         # the data gradient lives on the up-sampled grid; its 2x2 sums go straight to the half-resolution
                         # gradient in the kernel epilogue (no full-resolution temporary, no separate pass)
                         self.bwd.append(Launch("mi355_conv2d_igemm", dy, wb, None, xg, x.N, Ho, Wo, Co, dy.ld, 2 * x.H, 2 * x.W,

@@ -156,15 +156,21 @@ class GpuBatchLoader:
         n = len(self.dataset)
         return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
 
-    def __iter__(self):
+    def epoch_batches(self):
+        """The index batches of one epoch, in order (draws this epoch's permutation when shuffling)."""
         n = len(self.dataset)
         order = torch.randperm(n, generator=self.gen).tolist() if self.shuffle else list(range(n))
+        return [order[b * self.batch_size:(b + 1) * self.batch_size] for b in range(len(self))]
+
+    def load(self, idxs):
+        """One device batch (x, y) of the samples ``idxs``: native PNG decode into pinned memory, transforms on the GPU."""
         tf = self.dataset.transform
-        for b in range(len(self)):
-            idxs = order[b * self.batch_size:(b + 1) * self.batch_size]
-            if self.dataset.is_seg:
-                imgs, masks = self.dataset.load_batch(idxs, self.threads)
-                yield tf(imgs.to(self.device, non_blocking=True), masks.to(self.device, non_blocking=True))
-            else:
-                imgs, labels = self.dataset.load_batch(idxs, self.threads)
-                yield tf(imgs.to(self.device, non_blocking=True)), labels.to(self.device, non_blocking=True)
+        if self.dataset.is_seg:
+            imgs, masks = self.dataset.load_batch(idxs, self.threads)
+            return tf(imgs.to(self.device, non_blocking=True), masks.to(self.device, non_blocking=True))
+        imgs, labels = self.dataset.load_batch(idxs, self.threads)
+        return tf(imgs.to(self.device, non_blocking=True)), labels.to(self.device, non_blocking=True)
+
+    def __iter__(self):
+        for idxs in self.epoch_batches():
+            yield self.load(idxs)

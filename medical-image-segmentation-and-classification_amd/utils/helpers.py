@@ -7,7 +7,13 @@ or fp16 with the device-side ``mi355.amp.GradScaler`` in the place of ``torch.am
 helpers.py:285,323-336) instead of autocast, the per-step ``loss.item()`` host syncs (helpers.py:337,341) are replaced
 by device-side accumulation read back once per epoch, and model factories construct the local
 classes directly (the reference first tries a torch.hub download, helpers.py:158-166, which has
-no network here)."""
+no network here).
+
+Data parallel: when ``torch.distributed`` is initialised with more than one rank (``torchrun --nproc-per-node N
+utils/trainer.py ...``), ``train()`` shards the loaders' batches by rank (utils/distributed.py), wraps the model in
+``mi355.dp.DataParallel`` (bucketed RCCL all-reduce of the flat gradient buffer overlapped with backward, 1/world folded
+into clip / AdamW), sums the epoch's loss / metric accumulators over ranks with one collective per pass, and lets rank 0
+alone print and write checkpoints; every rank returns the same ``best_score`` and stops early at the same epoch."""
 import math
 import os
 import time
@@ -19,6 +25,7 @@ from mi355 import amp as mamp
 from mi355 import nn as mnn
 from mi355 import optim as moptim
 from mi355.lib import lib
+from utils.distributed import RankShard, all_reduce_sums, dist_info
 
 CLASSES = ["COVID", "Healthy", "Non-COVID"]
 
@@ -115,12 +122,28 @@ def train(model, train_dl, val_dl, device, epochs, lr, name, save_dir, seg=False
     criterion = mnn.BCEWithLogitsLoss() if seg else mnn.CrossEntropyLoss(label_smoothing=0.1)
     STAGE1 = 5
 
+    # data parallel (module docstring): the reference's loop on this rank's batches, gradients averaged over ranks
+    rank, world = dist_info()
+    dp, inv_scale = None, 1.0
+    say = print if rank == 0 else (lambda *a, **k: None)
+    n_train, n_val, n_val_batches = len(train_dl.dataset), len(val_dl.dataset), len(val_dl)
+    if world > 1:
+        from mi355.dp import DataParallel
+        dp = DataParallel(model)                      # replicas start from rank 0's parameters and buffers
+        inv_scale = dp.inv_scale
+        train_dl, val_dl = RankShard(train_dl, rank, world, pad=True), RankShard(val_dl, rank, world, pad=False)
+
+    def make_optimizer(params, lr_):
+        opt = _make_optimizer(params, lr_)
+        opt.inv_scale = inv_scale                     # gradient averaging over ranks is folded into clip + AdamW
+        return opt
+
     if seg:
-        optimizer = _make_optimizer(model.parameters(), lr)
-        print(f"Training Segmentation model (all layers unfrozen) with LR: {lr}")
+        optimizer = make_optimizer(model.parameters(), lr)
+        say(f"Training Segmentation model (all layers unfrozen) with LR: {lr}")
         scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=epochs)
     else:
-        print(f"--- STAGE 1: Feature Extraction (Epochs 1-{STAGE1}) ---")
+        say(f"--- STAGE 1: Feature Extraction (Epochs 1-{STAGE1}) ---")
         for p in model.parameters():
             p.requires_grad = False
         head_params = []
@@ -128,7 +151,7 @@ def train(model, train_dl, val_dl, device, epochs, lr, name, save_dir, seg=False
             for p in getattr(model, cls_head_name).parameters():
                 p.requires_grad = True
                 head_params.append(p)
-        optimizer = _make_optimizer(head_params, 1e-4)
+        optimizer = make_optimizer(head_params, 1e-4)
         scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=STAGE1)
 
     # helpers.py:285 — scaling is enabled exactly where the reference's autocast would compute in fp16
@@ -137,21 +160,21 @@ def train(model, train_dl, val_dl, device, epochs, lr, name, save_dir, seg=False
     best_score = float("inf") if seg else 0.0
     patience, stale = 10, 0
     t0 = time.time()
-    n_train, n_val = len(train_dl.dataset), len(val_dl.dataset)
 
     for epoch in range(1, epochs + 1):
         if not seg and epoch == STAGE1 + 1:
-            print(f"\n--- STAGE 2: Full Fine-Tuning (Epochs {epoch}-{epochs}) ---")
+            say(f"\n--- STAGE 2: Full Fine-Tuning (Epochs {epoch}-{epochs}) ---")
             for p in model.parameters():
                 p.requires_grad = True
-            optimizer = _make_optimizer(model.parameters(), lr)
+            optimizer = make_optimizer(model.parameters(), lr)
             scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, mode="max", factor=0.1, patience=3)
-            print(f"Full fine-tuning (all layers unfrozen) with very low LR: {lr}. Using ReduceLROnPlateau scheduler.")
+            say(f"Full fine-tuning (all layers unfrozen) with very low LR: {lr}. Using ReduceLROnPlateau scheduler.")
 
         model.train()
         loss_sum = torch.zeros((), device=device)
         hit_sum = torch.zeros((), device=device)
         seen = 0
+        seen_all = 0                                  # samples this rank trained on (padding batches of the last step included)
         for x, y in train_dl:
             x, y = x.to(device, non_blocking=True), y.to(device, non_blocking=True)
             optimizer.zero_grad(set_to_none=True)
@@ -161,14 +184,17 @@ def train(model, train_dl, val_dl, device, epochs, lr, name, save_dir, seg=False
             loss = criterion(out, y)
             scaler.scale(loss).backward()
             scaler.unscale_(optimizer)
-            moptim.clip_grad_norm_(model.parameters(), max_norm=1.0)
+            moptim.clip_grad_norm_(model.parameters(), max_norm=1.0, inv_scale=inv_scale)
             scaler.step(optimizer)
             scaler.update()
             loss_sum += loss.detach() * x.size(0)
+            seen_all += x.size(0)
             if not seg:
                 hit_sum += (torch.argmax(out.detach(), 1) == y).sum()
                 seen += y.size(0)
 
+        if dp is not None:
+            dp.sync_buffers()                         # rank 0's BatchNorm statistics everywhere: one model is validated and saved
         model.eval()
         vloss = torch.zeros((), device=device)
         vmetric = torch.zeros((), device=device)
@@ -184,19 +210,26 @@ def train(model, train_dl, val_dl, device, epochs, lr, name, save_dir, seg=False
                 else:
                     vmetric += (torch.argmax(out, 1) == y).sum()
 
-        # one host read-back per epoch
-        train_loss = loss_sum.item() / n_train
+        # one host read-back per epoch (data parallel: one collective over the five accumulators first; the padded last
+        # optimiser step makes the number of samples trained on larger than the dataset, so the mean divides by what was seen)
+        if dp is not None:
+            cnt = torch.tensor([float(seen_all), float(seen)], device=device, dtype=torch.float64)
+            loss_sum, hit_sum, vloss, vmetric, seen_all_t, seen_t = all_reduce_sums(loss_sum, hit_sum, vloss, vmetric, cnt[0], cnt[1])
+            n_train_seen, seen = int(seen_all_t.item()), int(seen_t.item())
+        else:
+            n_train_seen = n_train
+        train_loss = loss_sum.item() / n_train_seen
         val_loss = vloss.item() / n_val
         if seg:
-            val_iou = vmetric.item() / len(val_dl)
+            val_iou = vmetric.item() / n_val_batches
             score = val_loss
-            print(f"[{name}] Ep{epoch}: TrainLoss {train_loss:.3f} | ValLoss {val_loss:.3f} | IoU {val_iou:.3f}")
+            say(f"[{name}] Ep{epoch}: TrainLoss {train_loss:.3f} | ValLoss {val_loss:.3f} | IoU {val_iou:.3f}")
             improved = val_loss < best_score
         else:
             train_acc = 100 * hit_sum.item() / max(seen, 1)
             val_acc = 100 * vmetric.item() / n_val
             score = val_acc
-            print(f"[{name}] Ep{epoch}: TrainLoss {train_loss:.3f} (Acc {train_acc:.2f}%) | ValLoss {val_loss:.3f} | ValAcc {val_acc:.2f}%")
+            say(f"[{name}] Ep{epoch}: TrainLoss {train_loss:.3f} (Acc {train_acc:.2f}%) | ValLoss {val_loss:.3f} | ValAcc {val_acc:.2f}%")
             improved = val_acc > best_score
 
         if seg or epoch <= STAGE1:
@@ -206,14 +239,15 @@ def train(model, train_dl, val_dl, device, epochs, lr, name, save_dir, seg=False
 
         if improved:
             best_score, stale = score, 0
-            os.makedirs(save_dir, exist_ok=True)
-            fname = f"{name}_best_loss.pt" if seg else f"{name}_best_acc.pt"
-            torch.save(model.state_dict(), os.path.join(save_dir, fname))
+            if rank == 0:
+                os.makedirs(save_dir, exist_ok=True)
+                fname = f"{name}_best_loss.pt" if seg else f"{name}_best_acc.pt"
+                torch.save(model.state_dict(), os.path.join(save_dir, fname))
         else:
             stale += 1
         if stale >= patience:
-            print(f"Early stopping at epoch {epoch}. Best score: {best_score:.2f}")
+            say(f"Early stopping at epoch {epoch}. Best score: {best_score:.2f}")
             break
 
-    print(f"Training for {name} finished in {(time.time() - t0) / 60:.2f} minutes.")
+    say(f"Training for {name} finished in {(time.time() - t0) / 60:.2f} minutes.")
     return best_score

@@ -11,6 +11,13 @@ defaults to synthetic 256x256 batches so that it runs anywhere:
 With ``--data-root dataset`` (the reference's DATA_ROOT layout: ``splits/train.csv``, ``<class>/images|masks/<id>.png``) it reads the
 real files instead: two dataset objects per task with the train / val transforms, one 80/20 index split shared by both
 (trainer.py:119-151), PNGs decoded by native threads and transformed on the GPU (utils/dataset.py, utils/gpu_transforms.py).
+
+Data parallel (BASELINE.json north star; the reference is single-device): one process per GPU,
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 utils/trainer.py --task seg ...
+
+The script joins the RCCL process group (backend "nccl"), draws the 80/20 split from a seed rank 0 broadcasts, and ``train()``
+does the rest: batches sharded by rank, gradients all-reduced over xGMI during backward, rank 0 prints and saves.
 """
 import argparse
 import os
@@ -58,9 +65,21 @@ def main():
     ap.add_argument("--save-dir", default="weights")
     ap.add_argument("--data-root", default=None, help="dataset directory in the reference's layout; default: synthetic batches")
     args = ap.parse_args()
-    device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
-    if device.type != "cuda":
+    if not torch.cuda.is_available():
         raise SystemExit("the MI355X path needs a GPU (no CPU fallback)")
+    # one process per GPU under torch.distributed.run: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the launcher
+    world, rank, local_rank = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    split_gen = None                                      # (single process: unseeded, like the reference's random_split)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+        seed = [int(torch.randint(0, 2 ** 31 - 1, (1,)))]
+        dist.broadcast_object_list(seed, src=0)          # every rank must cut the SAME 80/20 split
+        split_gen = torch.Generator().manual_seed(seed[0])
+    say = print if rank == 0 else (lambda *a, **k: None)
     results = {}
     for task in (["cls", "seg"] if args.task == "both" else [args.task]):
         names = [args.model] if args.model else (CLS_MODELS if task == "cls" else SEG_MODELS)
@@ -72,19 +91,20 @@ def main():
             ds_tr = DS(args.data_root, TF(args.size, train=True, device=device), "train")
             ds_va = DS(args.data_root, TF(args.size, train=False, device=device), "train")
             if len(ds_tr) == 0:
-                print(f"{task} dataset is empty under {args.data_root}. Skipping.")
+                say(f"{task} dataset is empty under {args.data_root}. Skipping.")
                 continue
             n_train = int(0.8 * len(ds_tr))
-            perm = torch.randperm(len(ds_tr)).tolist()            # (unseeded, like the reference's random_split)
+            perm = torch.randperm(len(ds_tr), generator=split_gen).tolist()      # (unseeded, like the reference's random_split)
             train_dl = GpuBatchLoader(ds_tr, bs, shuffle=True, device=device, indices=perm[:n_train])
             val_dl = GpuBatchLoader(ds_va, bs, shuffle=True, device=device, indices=perm[n_train:])
         else:
             full = synthetic_dataset(task, args.samples, args.size)
             n_train = int(0.8 * len(full))
-            tr, va = random_split(full, [n_train, len(full) - n_train])
+            tr, va = random_split(full, [n_train, len(full) - n_train], generator=split_gen) if split_gen is not None else \
+                random_split(full, [n_train, len(full) - n_train])
             train_dl, val_dl = make_loader(tr, bs, True), make_loader(va, bs, False)
         for name in names:
-            print(f"\n{'=' * 20} {task.upper()} :: {name} {'=' * 20}")
+            say(f"\n{'=' * 20} {task.upper()} :: {name} {'=' * 20}")
             if task == "cls":
                 model, head = get_class_model(name)
                 best = train(model, train_dl, val_dl, device, args.epochs, args.lr, name, os.path.join(args.save_dir, "classification_models"),
@@ -93,9 +113,11 @@ def main():
                 model = get_seg_model(name)
                 best = train(model, train_dl, val_dl, device, args.epochs, args.lr, name, os.path.join(args.save_dir, "segmentation_models"), seg=True)
             results[(task, name)] = best
-    print("\n===== SUMMARY =====")
+    say("\n===== SUMMARY =====")
     for (task, name), best in results.items():
-        print(f"{task:>4} {name:<14} best {'val loss' if task == 'seg' else 'val acc'}: {best:.4f}")
+        say(f"{task:>4} {name:<14} best {'val loss' if task == 'seg' else 'val acc'}: {best:.4f}")
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -612,6 +612,57 @@ def test_attention_gate_tail(dtype, c):
     assert abs(float(db[0]) - float(bp.grad)) < 1e-3 * float(wp.grad.abs().max()) + 1e-5   # ~0 (BN follows)
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("nhw,f", [((2, 37, 41), 64), ((1, 5, 7), 96), ((2, 37, 41), 96), ((3, 16, 16), 128)])
+def test_gate_multiply_backward_accumulating_ragged_and_odd_chunk_counts(nhw, f, dtype):
+    """mi355_gate_mul_fwd / _bwd on the paths the attention-gate test above does not reach: accumulate = 1 into a pre-filled
+    gradient (the skip tensor has other consumers, AttentionUNet.py:101-116), row counts that are no multiple of the kernel's
+    row groups (2 x 37 x 41, 35 rows: clamped tail loads), channel counts whose 16-byte chunk count is not a power of two
+    (96 channels: idle lanes in every row group), also through rowdot_fwd's clamped chunk loads."""
+    n, h, w = nhw
+    code = DTYPE_CODE[dtype]
+    g = torch.Generator().manual_seed(f + h)
+    m = n * h * w
+    x = q(torch.randn(n, f, h, w, generator=g), dtype)
+    z = torch.randn(m, generator=g)
+    dout = q(torch.randn(n, f, h, w, generator=g), dtype)
+    pre = q(torch.randn(n, f, h, w, generator=g), dtype)
+    gam, bet = 1.3, -0.2
+    mu, var = z.mean(), z.var(unbiased=False)
+    isd = 1.0 / torch.sqrt(var + 1e-5)
+    sc_, sh_ = gam * isd, bet - gam * isd * mu
+    psi = torch.sigmoid(z * sc_ + sh_).view(n, 1, h, w)
+    xd, dyd = to_nhwc(x, dtype), to_nhwc(dout, dtype)
+    zd, scd, shd, mud, isdd = dev(z), dev(sc_.view(1)), dev(sh_.view(1)), dev(mu.view(1)), dev(isd.view(1))
+    od = torch.empty_like(xd)
+    lib.mi355_gate_mul_fwd(xd, f, zd, scd, shd, od, f, m, f, code)
+    dzn = torch.empty(m, device=DEV)
+    nb, part = _partials(m, 1)
+    for acc in (0, 1):
+        dxd = to_nhwc(pre, dtype).clone()
+        lib.mi355_gate_mul_bwd(dyd, f, xd, f, zd, scd, shd, mud, isdd, dxd, f, acc, dzn, part, m, f, code)
+        torch.cuda.synchronize()
+        want = dout * psi + (pre if acc else 0)
+        assert rel_err(from_nhwc(dxd), want) < TOL[dtype], acc
+    ref_dzn = ((dout * x).sum(1, keepdim=True) * psi * (1 - psi)).flatten()
+    assert rel_err(from_nhwc(od), x * psi) < TOL[dtype]
+    assert rel_err(dzn.cpu(), ref_dzn) < (1e-4 if dtype == torch.float32 else 2e-2)
+    sums = torch.empty(2, device=DEV); dg = torch.zeros(1, device=DEV); db = torch.zeros(1, device=DEV)
+    lib.mi355_bn_bwd_finalize(part, nb, 1, sums, dg, db, 0.0)
+    torch.cuda.synchronize()
+    zhat = (z - mu) * isd
+    assert abs(float(db) - float(ref_dzn.sum())) <= 2e-2 * float(ref_dzn.abs().sum()) + 1e-5
+    assert abs(float(dg) - float((ref_dzn * zhat).sum())) <= 2e-2 * float((ref_dzn * zhat).abs().sum()) + 1e-5
+    # rowdot_fwd with the same ragged / odd-chunk geometry (its chunk loads are clamped the same way)
+    wp = torch.randn(f, generator=g) / math.sqrt(f)
+    zz = torch.empty(m, device=DEV)
+    nb2, part2 = _partials(m, 1)
+    lib.mi355_rowdot_fwd(xd, f, dev(wp), dev(torch.tensor([0.25])), zz, part2, m, f, 0, 1, code)
+    torch.cuda.synchronize()
+    ref = (x * wp.view(1, f, 1, 1)).sum(1).flatten() + 0.25
+    assert rel_err(zz.cpu(), ref) < (1e-4 if dtype == torch.float32 else 2e-2)
+
+
 def test_heads_and_losses():
     g = torch.Generator().manual_seed(8)
     n, c, hw = 3, 96, 20

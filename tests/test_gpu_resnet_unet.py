@@ -140,3 +140,27 @@ def test_frozen_weight_packs_follow_the_parameters():
     m.load_state_dict(sd)                                                                          # back to the original weights
     o3 = m(xd).detach()
     assert float((o3 - o1).abs().max()) <= 1e-6 * float(o1.abs().max())
+    # Writers autograd's version counters do not see — a collective into the flat buffer (DataParallel.sync_state: dist.broadcast),
+    # a ``.data`` edit — go through Engine.invalidate_packs(); without it the frozen layers would keep running the old packs.
+    sig = plan._static_sig
+    w.data.mul_(1.25)
+    assert (plan.flat_p._version, sum(p._version for p in plan.static_params)) == sig[:2]          # invisible to the counters ...
+    m.engine.invalidate_packs()
+    o4 = m(xd).detach().clone()
+    assert plan._static_sig != sig and float((o4 - o2_ref).abs().max()) <= 1e-6 * float(o2_ref.abs().max())
+    # ... and a data-parallel state sync does that itself (one rank: the broadcast is the identity, the epoch still moves)
+    import torch.distributed as dist
+    from mi355.dp import DataParallel
+    import socket
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        dp = DataParallel(m)
+        epoch = m.engine.pack_epoch
+        w.data.mul_(1 / 1.25)
+        dp.sync_state()
+        assert m.engine.pack_epoch == epoch + 1
+        o5 = m(xd).detach()
+        assert float((o5 - o1).abs().max()) <= 2e-6 * float(o1.abs().max())
+    finally:
+        dist.destroy_process_group()

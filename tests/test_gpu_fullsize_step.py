@@ -1,0 +1,109 @@
+"""-m gpu: ONE train step at the BENCHMARK shape against the CPU oracle (closes the gap "parity at benchmark scale stops at
+the eval forward": tests/test_gpu_bench_scale.py compares the 2-byte runs with the fp32 run of the SAME kernels).
+
+AttentionUNet 256 x 256, batch 32 (BASELINE.json configs[2]) — and R2AttU_Net 256 x 256, batch 16 (configs[3]) — in fp32 on
+the HIP path: forward in train mode (M = 2 097 152 rows through the statistic folds, one row per persistent workgroup), BCE,
+the whole backward (split weight gradients, every BatchNorm backward pass at its 1 024-workgroup cap, the fused gate / head /
+pool passes).  The oracle evaluates the same step in fp32 on the host cores with the ReLU masks and max-pool decisions the
+GPU ACTUALLY took replayed (oracle.nets.Kinks; without the replay any two fp32 evaluations differ by ~1e-3 per flipped mask,
+tests/test_gpu_kinks.py).  Asserted, all relative to the tensor's maximum: loss, the train-mode logits of the first and last
+image, every BatchNorm running_mean / running_var, and EVERY parameter-gradient tensor within 1e-3 (north star: "within 1e-3
+relative fp32"); the measured maxima are printed.  Reference: /root/reference/models/segmentation_models/AttentionUNet.py:86-121,
+R2AttU_Net.py:119-158, utils/helpers.py:320-336."""
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import gpu_kinks
+from oracle import nets
+from oracle import train as otrain
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+
+
+def _he_state(name):
+    sd = nets.default_init_state(name, seed=0)
+    for v in sd.values():
+        if v.dim() == 4:
+            v.mul_(6 ** 0.5)          # (as tests/bench_scale_worker.py: activations stay O(1) through 26 layers)
+    return sd
+
+
+CASES = {
+    # name -> (helpers key, state, batch, size)
+    "AttentionUNet": ("attentionunet", lambda: _he_state("AttentionUNet"), 32, 256),
+    "R2AttU_Net": ("r2attunet", lambda: nets.closed_form_state("R2AttU_Net"), 16, 256),
+}
+
+
+@pytest.mark.parametrize("name", ["AttentionUNet", "R2AttU_Net"])
+def test_full_size_fp32_train_step_matches_the_cpu_oracle(name):
+    import bench
+    from mi355 import nn as mnn
+    from utils.helpers import get_seg_model
+    key, state, bs, hw = CASES[name]
+    sd = state()
+    x, y = bench.make_batch(bs, hw, seed=0, device="cpu")
+    t0 = time.time()
+    m = get_seg_model(key)
+    m.load_state_dict(sd)
+    m.compute_dtype = torch.float32
+    m = m.to(DEV).train()
+    out = m(x.to(DEV))
+    loss = mnn.BCEWithLogitsLoss()(out, y.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    relu, pool = gpu_kinks(out._mi355_plan)
+    got = {"loss": float(loss.detach()), "first": out[0].detach().cpu(), "last": out[-1].detach().cpu(),
+           "grads": {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters() if p.grad is not None},
+           "buffers": {k: v.detach().cpu().clone() for k, v in m.state_dict().items() if nets.is_buffer(k)}}
+    n_params = sum(1 for _ in m.parameters())
+    del m, out, loss
+    torch.cuda.empty_cache()
+    t1 = time.time()
+
+    # the same step on the host, fp32, the GPU's kink decisions replayed (the state dict's running statistics are updated in place)
+    ref_sd = {k: v.clone() for k, v in sd.items()}
+    nets.Kinks.start("replay", relu, pool)
+    try:
+        ref_loss, ref_out, ref_g = otrain.forward_backward(name, ref_sd, x, y, True)
+    finally:
+        _, _, used = nets.Kinks.stop()
+    assert used == (len(relu), len(pool)), (used, len(relu), len(pool))
+    del relu, pool
+    t2 = time.time()
+
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / max(float(b.double().abs().max()), 1e-30))
+    assert abs(got["loss"] - ref_loss) <= 1e-3 * abs(ref_loss), (got["loss"], ref_loss)
+    e_first, e_last = rel(got["first"], ref_out[0]), rel(got["last"], ref_out[-1])
+    assert e_first <= 1e-3 and e_last <= 1e-3, (e_first, e_last)
+    e_buf = {}
+    for k, v in got["buffers"].items():
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == int(ref_sd[k]), k
+        else:
+            e_buf[k] = rel(v, ref_sd[k])
+    worst_b = max(e_buf, key=e_buf.get)
+    assert e_buf[worst_b] <= 1e-3, (worst_b, e_buf[worst_b])
+    gmax = max(float(v.abs().max()) for v in ref_g.values())
+    assert len(got["grads"]) == n_params == len(ref_g)
+    e_g = {}
+    for k, g in got["grads"].items():
+        sc = float(ref_g[k].abs().max())
+        if sc < 1e-6 * gmax:                            # a conv bias in front of a train-mode BatchNorm: exactly zero
+            assert float(g.abs().max()) <= 1e-5 * gmax, k
+            continue
+        e_g[k] = float((g.double() - ref_g[k].double()).abs().max()) / sc
+    e = np.array(list(e_g.values()))
+    worst = max(e_g, key=e_g.get)
+    print(f"\n[{name} {bs}x{hw}x{hw} fp32 step vs CPU oracle, {len(e)} gradient tensors] loss {got['loss']:.6f} vs {ref_loss:.6f}; logits "
+          f"{e_first:.1e} / {e_last:.1e}; BN buffers max {e_buf[worst_b]:.1e} ({worst_b}); gradients median {np.median(e):.1e} "
+          f"max {e.max():.1e} ({worst}); GPU + read-back {t1 - t0:.0f} s, oracle {t2 - t1:.0f} s")
+    assert e.max() <= 1e-3, (worst, e_g[worst], float(np.median(e)))

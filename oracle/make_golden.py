@@ -15,9 +15,13 @@ helpers.py:14,52-118) for ``utils.helpers``; ``cv2``, ``albumentations``
 ``models.segmentation_models.ResnetUnet`` — of which only the metric functions,
 the two eval loops, the report writers (tester.py:92-312, 738-876), the two
 ``Pipeline._predict_*`` methods (pipeline.py:324-357) and ``DecoderBlock``
-(ResnetUnet.py:17-27) are run: none of them reaches a stubbed module.  The
-torchvision ENCODERS (``ResNetUnet.__init__``, the hub models) and the
-Albumentations transforms do need the real libraries and stay unpinned.
+(ResnetUnet.py:17-27) are run: none of them reaches a stubbed module.
+``ResNetUnet`` itself (ResnetUnet.py:29-83) runs with ``torchvision.models.resnet50``
+answered by a plain-torch container of torchvision's public layout
+(``_TvResNet50`` below): its constructor, ``_freeze_backbone`` and forward wiring
+are the reference's own code, the ENCODER is ours and stays declared unpinned, as
+do the hub models' layouts and the Albumentations transforms (they need the real
+libraries).
 ``utils.tester`` creates ``./results`` at import time (tester.py:38): the
 generator changes into a scratch directory first.
 """
@@ -426,6 +430,116 @@ def pipeline_fixture(C, H):
     print("pipeline: pred", preds, "conf", [round(c, 2) for c in confs], "mask px", [int((m > 0).sum()) for m in masks])
 
 
+class _TvBottleneck(torch.nn.Module):
+    """Stand-in for torchvision's ResNet ``Bottleneck`` (v1.5: the stride sits on the 3x3) — a plain torch.nn container with
+    torchvision's PUBLIC attribute names (conv1 / bn1 / conv2 / bn2 / conv3 / bn3 / relu / downsample), written from the
+    published architecture because torchvision is absent here.  Test infrastructure of resnet_unet_fixture() only: it lets the
+    REFERENCE's ResNetUnet.__init__ / forward / _freeze_backbone (ResnetUnet.py:29-83) run as they are.  The encoder itself
+    stays declared unpinned (this class is ours); what the fixture pins is the reference's wiring around it."""
+
+    def __init__(self, inplanes, planes, stride, downsample):
+        super().__init__()
+        nn = torch.nn
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idn = x if self.downsample is None else self.downsample(x)
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.relu(self.bn2(self.conv2(y)))
+        return self.relu(self.bn3(self.conv3(y)) + idn)
+
+
+class _TvResNet50(torch.nn.Module):
+    """... and of ``torchvision.models.resnet50``'s trunk: conv1 / bn1 / relu / maxpool / layer1..4 (the attributes
+    ResnetUnet.py:34-43 takes; avgpool / fc are never touched there)."""
+
+    def __init__(self):
+        super().__init__()
+        nn = torch.nn
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        inplanes = 64
+        for i, (planes, blocks, stride) in enumerate(((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)), start=1):
+            layers = []
+            for b in range(blocks):
+                s = stride if b == 0 else 1
+                ds = None
+                if b == 0 and (s != 1 or inplanes != planes * 4):
+                    ds = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=s, bias=False), nn.BatchNorm2d(planes * 4))
+                layers.append(_TvBottleneck(inplanes, planes, s, ds))
+                inplanes = planes * 4
+            setattr(self, f"layer{i}", nn.Sequential(*layers))
+
+
+def resnet_unet_fixture():
+    """The REFERENCE's ``ResNetUnet`` (ResnetUnet.py:29-83) run as it is — constructor, ``_freeze_backbone``, forward wiring (skip
+    order, DecoderBlock inputs, decoder1, the 1x1 head) — with ``torchvision.models.resnet50(weights=ResNet50_Weights.DEFAULT)``
+    answered by the plain-torch container above (no download, closed-form weights loaded afterwards).  Stored, for freeze=True and
+    freeze=False: eval and train logits, the loss, the ``requires_grad`` pattern, which parameters received a gradient, every
+    BatchNorm buffer after ONE train-mode forward (a frozen encoder still updates its running statistics: model.train() is
+    global, helpers.py:315), per-parameter gradient norms, and the parameters after clip(1.0) + AdamW over ALL parameters
+    (helpers.py:251,333: frozen ones have no .grad and are skipped by torch)."""
+    _ref_tester_pipeline()                                # installs the empty torchvision stand-ins and imports ResnetUnet
+    tvm = sys.modules["torchvision.models"]
+    calls = []
+    tvm.ResNet50_Weights = type("ResNet50_Weights", (), {"DEFAULT": "IMAGENET1K_V2"})
+
+    def resnet50(weights=None, **kw):
+        calls.append(weights)
+        return _TvResNet50()
+    tvm.resnet50 = resnet50
+    from models.segmentation_models.ResnetUnet import ResNetUnet
+    rec = {}
+    x, mask = otrain.closed_form_input(2, 64)
+    for freeze in (True, False):
+        tag = "frozen" if freeze else "unfrozen"
+        m = ResNetUnet(n_classes=1, freeze=freeze)
+        assert calls[-1] == "IMAGENET1K_V2"               # the reference asked for the default pretrained weights
+        sd = nets.closed_form_state("ResNetUnet")
+        missing = m.load_state_dict(sd, strict=True)
+        names = [k for k, _ in m.named_parameters()]
+        m.eval()
+        with torch.no_grad():
+            rec[f"{tag}/logits_eval"] = m(x).numpy()
+        m.train()
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=5e-4)
+        opt.zero_grad(set_to_none=True)
+        out = m(x)
+        loss = torch.nn.BCEWithLogitsLoss()(out, mask)
+        loss.backward()
+        params = dict(m.named_parameters())
+        rec[f"{tag}/logits_train"] = out.detach().numpy()
+        rec[f"{tag}/loss"] = float(loss)
+        rec[f"{tag}/param_names"] = np.array(names)
+        rec[f"{tag}/requires_grad"] = np.array([params[k].requires_grad for k in names])
+        rec[f"{tag}/has_grad"] = np.array([params[k].grad is not None for k in names])
+        rec[f"{tag}/grad_norm"] = np.array([float(params[k].grad.double().norm()) if params[k].grad is not None else -1.0 for k in names])
+        rec[f"{tag}/gradfull/out.weight"] = params["out.weight"].grad.clone().numpy()                  # (before the clip scales them)
+        rec[f"{tag}/gradfull/decoder2.up_sample.weight"] = params["decoder2.up_sample.weight"].grad[::4, ::4].clone().numpy()
+        rec[f"{tag}/total_grad_norm"] = float(torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0))
+        opt.step()
+        after = m.state_dict()
+        bufs = [k for k in after if nets.is_buffer(k)]
+        rec[f"{tag}/buffer_names"] = np.array(bufs)
+        rec[f"{tag}/buffer_l2"] = np.array([float(after[k].double().norm()) for k in bufs])
+        rec[f"{tag}/param_l2_after"] = np.array([float(after[k].double().norm()) for k in names])
+        rec[f"{tag}/param_moved"] = np.array([float((after[k].double() - sd[k].double()).abs().max()) for k in names])
+        for k in ("encoder1.1.running_mean", "encoder5.2.bn3.running_var", "decoder5.basic_block.1.running_mean", "decoder1.2.running_var"):
+            rec[f"{tag}/full/{k}"] = after[k].numpy()
+        print(f"ResNetUnet {tag}: loss {float(loss):.6f} |g| {rec[f'{tag}/total_grad_norm']:.4f} frozen {int((~rec[f'{tag}/requires_grad']).sum())} / {len(names)}")
+    rec["state_keys"] = np.array(list(m.state_dict().keys()))
+    np.savez_compressed(os.path.join(OUT, "model_ResNetUnet.npz"), **rec)
+
+
 def cls_metric_fixture():
     """utils/tester.py:49-88 ``calculate_classification_metrics`` is six scikit-learn calls (accuracy_score; precision_ /
     recall_ / f1_score with average="weighted" and average=None, zero_division=0; confusion_matrix).  tester.py itself
@@ -602,6 +716,7 @@ def main(only=()):
         "ResNet50": lambda: model_fixture("ResNet50", lambda: C["ResNet50"](num_classes=1000), 64, False, head_dropout=True, H=H),
         "VGG16": lambda: model_fixture("VGG16", lambda: C["VGG16"](num_classes=1000), 32, False, head_dropout=True, H=H),
         "VGG19": lambda: model_fixture("VGG19", lambda: C["VGG19"](num_classes=1000), 32, False, head_dropout=True, H=H),
+        "ResNetUnet": resnet_unet_fixture,
         "train_traj_seg": lambda: train_traj_seg(C, H),
         "train_traj_R2AttU_Net": lambda: train_traj_seg(C, H, "R2AttU_Net", lr=1e-5, hw=64),
         "train_traj_R2U_Net": lambda: train_traj_seg(C, H, "R2U_Net", lr=1e-5, hw=64),

@@ -94,16 +94,19 @@ def test_full_size_fp32_train_step_matches_the_cpu_oracle(name):
     assert e_buf[worst_b] <= 1e-3, (worst_b, e_buf[worst_b])
     gmax = max(float(v.abs().max()) for v in ref_g.values())
     assert len(got["grads"]) == n_params == len(ref_g)
-    e_g = {}
+    e_g, n_zero = {}, 0
     for k, g in got["grads"].items():
         sc = float(ref_g[k].abs().max())
-        if sc < 1e-6 * gmax:                            # a conv bias in front of a train-mode BatchNorm: exactly zero
-            assert float(g.abs().max()) <= 1e-5 * gmax, k
+        # A conv bias in front of a train-mode BatchNorm has a mathematically zero gradient (sum of dy over a normalised channel):
+        # the HIP plan never computes it (exact zeros), the oracle's autograd leaves the fp32 round-off of a 2-million-term sum.
+        if float(g.abs().max()) == 0.0 or sc < 1e-6 * gmax:
+            assert k.endswith(".bias") and sc <= 1e-4 * gmax and float(g.abs().max()) <= 1e-5 * gmax, (k, sc, gmax)
+            n_zero += 1
             continue
         e_g[k] = float((g.double() - ref_g[k].double()).abs().max()) / sc
     e = np.array(list(e_g.values()))
     worst = max(e_g, key=e_g.get)
-    print(f"\n[{name} {bs}x{hw}x{hw} fp32 step vs CPU oracle, {len(e)} gradient tensors] loss {got['loss']:.6f} vs {ref_loss:.6f}; logits "
+    print(f"\n[{name} {bs}x{hw}x{hw} fp32 step vs CPU oracle, {len(e)} gradient tensors + {n_zero} identically zero biases] loss {got['loss']:.6f} vs {ref_loss:.6f}; logits "
           f"{e_first:.1e} / {e_last:.1e}; BN buffers max {e_buf[worst_b]:.1e} ({worst_b}); gradients median {np.median(e):.1e} "
           f"max {e.max():.1e} ({worst}); GPU + read-back {t1 - t0:.0f} s, oracle {t2 - t1:.0f} s")
     assert e.max() <= 1e-3, (worst, e_g[worst], float(np.median(e)))

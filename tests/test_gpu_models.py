@@ -294,6 +294,27 @@ def test_resnet_unet_matches_oracle_fp32():
         if k.endswith(("running_mean", "running_var")):
             assert _rel(msd[k].cpu().numpy(), v.detach().numpy()) < 1e-4, k
 
+    # ... and the REFERENCE's own ResNetUnet (ResnetUnet.py:29-83 run over a plain-torch container of torchvision's layout,
+    # tests/golden/model_ResNetUnet.npz): logits, loss, which parameters are trainable / received a gradient, every BatchNorm
+    # buffer after the train-mode forward (the frozen encoder's too), the decoder's gradient norms (two fp32 evaluations with
+    # their own mask flips: bounds of 2-3x what is measured, as for the other model fixtures)
+    z = np.load(os.path.join(G, "model_ResNetUnet.npz"), allow_pickle=False)
+    names = [str(s_) for s_ in z["frozen/param_names"]]
+    assert names == [k for k, _ in m.named_parameters()] and [str(s_) for s_ in z["state_keys"]] == list(msd.keys())
+    assert np.array_equal(z["frozen/requires_grad"], np.array([params[k].requires_grad for k in names]))
+    assert np.array_equal(z["frozen/has_grad"], np.array([params[k].grad is not None for k in names]))
+    assert _rel(ev.numpy(), z["frozen/logits_eval"]) < RTOL
+    assert _rel(out.detach().cpu().numpy(), z["frozen/logits_train"]) < 5e-4
+    assert abs(float(loss.detach()) - float(z["frozen/loss"])) < 2e-5
+    bufs = [str(b) for b in z["frozen/buffer_names"]]
+    l2 = np.array([float(msd[k].double().norm()) for k in bufs])
+    assert np.allclose(l2, z["frozen/buffer_l2"], rtol=1e-4)
+    want = z["frozen/grad_norm"]
+    gn = np.array([float(params[k].grad.double().norm()) if params[k].grad is not None else -1.0 for k in names])
+    big = want > 1e-6 * want.max()
+    dev = np.abs(gn[big] / want[big] - 1)
+    assert np.median(dev) <= 2e-3 and dev.max() <= 5e-2, (np.median(dev), dev.max())
+
 
 def test_tester_functions_match_oracle_metrics(capsys):
     """utils.tester (tester.py:92-312 counterpart): metric helpers and the segmentation eval loop."""

@@ -248,3 +248,30 @@ def test_torchvision_resnet_layouts_have_the_published_sizes():
     assert sum(l.name == "mi355_bn_finalize" for l in plan.fwd) == 53      # 49 block BNs + 4 downsample, bn1 once
     local, _ = get_class_model("resnet50")
     assert "layer1.0.identity.0.weight" in local.state_dict()              # default: the reference's offline fallback classes
+
+
+@pytest.mark.parametrize("freeze", [True, False])
+def test_resnet_unet_layout_and_freeze_pattern_match_the_reference_class(freeze):
+    """models/segmentation_models/ResnetUnet.py against the REFERENCE's ResNetUnet (ResnetUnet.py:29-83 instantiated over a
+    plain-torch container of torchvision's ResNet-50 layout, tests/golden/model_ResNetUnet.npz): the same state_dict keys in the
+    same order, the same parameter order, the same requires_grad pattern after `_freeze_backbone` (ResnetUnet.py:60-66) — and the
+    launch plan gives a gradient to exactly the parameters the reference's backward gave one (frozen encoder: its weight- and
+    data-gradient launches are pruned, its BatchNorm statistic launches stay in the forward)."""
+    import os
+    import numpy as np
+    from models.segmentation_models.ResnetUnet import ResNetUnet
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "model_ResNetUnet.npz"), allow_pickle=False)
+    tag = "frozen" if freeze else "unfrozen"
+    net = ResNetUnet(n_classes=1, freeze=freeze)
+    assert list(net.state_dict().keys()) == [str(k) for k in z["state_keys"]]
+    names = [k for k, _ in net.named_parameters()]
+    assert names == [str(k) for k in z[f"{tag}/param_names"]]
+    assert np.array_equal(np.array([p.requires_grad for _, p in net.named_parameters()]), z[f"{tag}/requires_grad"])
+    net.train()
+    net.engine.flatten()
+    plan = net.engine.plan_for((2, 3, 64, 64), True, True, torch.float32)
+    got = {id(p) for p in plan.grad_params}
+    want = {id(p) for (k, p), h in zip(net.named_parameters(), z[f"{tag}/has_grad"]) if h}
+    assert got == want
+    n_bn = sum(isinstance(mod, torch.nn.BatchNorm2d) for mod in net.modules())
+    assert sum(l.name == "mi355_bn_finalize" for l in plan.fwd) == n_bn          # every BatchNorm runs in train mode, frozen or not

@@ -120,11 +120,13 @@ def profile_plan(plan, x, stream, reps=2):
             key = l.tag or l.name
             if SPLIT_BY_SHAPE and l.name in ("mi355_bn_act", "mi355_bn_bwd_reduce", "mi355_bn_bwd_apply"):
                 key = f"{l.name} M={l.args[-4]} C={l.args[-3]}"
-            a = agg.setdefault(key, [0.0, 0, 0.0, 0.0])
-            a[0] += e0.elapsed_time(e1)
+            a = agg.setdefault(key, [0.0, 0, 0.0, 0.0, 0.0])
+            dt = e0.elapsed_time(e1)
+            a[0] += dt
             a[1] += 1
             a[2] += l.flops
             a[3] += l.bytes
+            a[4] += dt * l.cus          # chip-time: a launch sized for half the CUs holds half the chip for its duration
     return agg
 
 
@@ -363,50 +365,58 @@ def main():
         global SPLIT_BY_SHAPE
         SPLIT_BY_SHAPE = args.split_by_shape
         agg = profile_plan(plan, x, torch.cuda.current_stream().cuda_stream)
-        total = sum(v[0] for v in agg.values())
-        ranked = sorted(agg.items(), key=lambda kv: -kv[1][0])
+        # Kernels are ranked by CHIP-TIME (duration x share of the CUs the launch is sized for, Launch.cus): every launch but the
+        # eight-wave weight gradient spans the chip; that one is launched on 128 CU-owning workgroups so that the main stream keeps
+        # the other 128 CUs (csrc/conv_wgrad.hip), and its fraction of peak is quoted for the whole chip AND for the CUs it holds.
+        total = sum(v[4] for v in agg.values())
+        ranked = sorted(agg.items(), key=lambda kv: -kv[1][4])
         if args.kernel_table:
-            print(f"{'kernel / launcher':58s} {'ms/step':>9s} {'launches':>8s} {'TFLOP/s':>9s} {'GB/s':>8s} {'share':>6s}", file=sys.stderr)
+            print(f"{'kernel / launcher':58s} {'ms/step':>9s} {'launches':>8s} {'TFLOP/s':>9s} {'GB/s':>8s} {'CUs':>5s} {'share':>6s}", file=sys.stderr)
             reps = 2
-            for k, (ms_, n, fl, nb_) in ranked[:args.table_rows]:
+            for k, (ms_, n, fl, nb_, chip) in ranked[:args.table_rows]:
                 tf = fl / (ms_ * 1e-3) / 1e12 if fl else 0.0
                 gbs = nb_ / (ms_ * 1e-3) / 1e9 if nb_ else 0.0      # algorithmic bytes / time
-                print(f"{k:58s} {ms_ / reps:9.3f} {n // reps:8d} {tf:9.1f} {gbs:8.0f} {ms_ / total:6.1%}", file=sys.stderr)
-            print(f"{'sum of plan launches':58s} {total / reps:9.3f}", file=sys.stderr)
-        k, (ms_, n, fl, nb) = ranked[0]
-        traffic, traffic_src = pmc_traffic(k)
-        if fl:
+                print(f"{k:58s} {ms_ / reps:9.3f} {n // reps:8d} {tf:9.1f} {gbs:8.0f} {chip / ms_:5.2f} {chip / total:6.1%}", file=sys.stderr)
+            print(f"{'sum of plan launches (ms; chip-time ms)':58s} {sum(v[0] for v in agg.values()) / reps:9.3f} {total / reps:9.3f}", file=sys.stderr)
+
+        def mfma_entry(k, ms_, n, fl, nb, chip):
             ach = fl / (ms_ * 1e-3) / 1e12
             peak = PEAK_TFLOPS[args.dtype]
-            result["roofline"] = {"bound": "mfma", "kernel": k, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                                  "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC)",
-                                  "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(nb / n),
-                                  "launch_timing": "HIP events around every launch of a single-stream replay of the plan (the "
-                                                   "production step overlaps weight-gradient kernels on a side stream)",
-                                  "launches_per_step": n // 2, "avg_launch_ms": round(ms_ / n, 4),
-                                  "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3),
-                                  "share_of_plan_time": round(ms_ / total, 3)}
+            cus = chip / ms_
+            e = {"kernel": k, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4)}
+            if cus < 0.999:      # sized for a share of the chip by design: the fraction of what THOSE CUs can deliver beside it
+                e.update({"cus_share": round(cus, 3), "frac_of_cus_used": round(ach / (peak * cus), 4)})
+            return e
+
+        k, (ms_, n, fl, nb, chip) = ranked[0]
+        traffic, traffic_src = pmc_traffic(k)
+        common = {"traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC)", "traffic_source": traffic_src,
+                  "launch_timing": "HIP events around every launch of a single-stream replay of the plan (the production step "
+                                   "overlaps weight-gradient kernels on a side stream); kernels ranked by chip-time = duration x "
+                                   "share of the CUs the launch is sized for",
+                  "launches_per_step": n // 2, "avg_launch_ms": round(ms_ / n, 4), "share_of_plan_time": round(chip / total, 3)}
+        if fl:
+            result["roofline"] = {**mfma_entry(k, ms_, n, fl, nb, chip), **common, "algorithmic_bytes_per_launch": int(nb / n),
+                                  "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3)}
         else:
             gbs = nb / (ms_ * 1e-3) / 1e9 if nb else None      # algorithmic bytes (each operand once) / launch time
             result["roofline"] = {"bound": "hbm", "kernel": k, "achieved": round(gbs, 1) if gbs else None, "peak": 8000.0, "unit": "GB/s",
-                                  "frac": round(gbs / 8000.0, 4) if gbs else None, "traffic": traffic, "traffic_source": traffic_src,
-                                  "algorithmic_bytes_per_launch": int(nb / n) if nb else None, "launches_per_step": n // 2,
-                                  "avg_launch_ms": round(ms_ / n, 4), "share_of_plan_time": round(ms_ / total, 3)}
+                                  "frac": round(gbs / 8000.0, 4) if gbs else None, **common,
+                                  "algorithmic_bytes_per_launch": int(nb / n) if nb else None}
         # the kernels behind the dominant one (same measurement): the step is not one kernel
         also = []
-        for k2, (ms2, n2, fl2, nb2) in ranked[1:7]:
+        for k2, (ms2, n2, fl2, nb2, chip2) in ranked[1:8]:
             t2, _ = pmc_traffic(k2)          # HBM bytes per launch from the same PMC file as the dominant kernel's (None: not in it)
-            extra = {"launches_per_step": n2 // 2, "share_of_plan_time": round(ms2 / total, 3), "avg_launch_ms": round(ms2 / n2, 4),
+            extra = {"launches_per_step": n2 // 2, "share_of_plan_time": round(chip2 / total, 3), "avg_launch_ms": round(ms2 / n2, 4),
                      "traffic": t2, "algorithmic_bytes_per_launch": int(nb2 / n2) if nb2 else None}
             if fl2:
-                a2 = fl2 / (ms2 * 1e-3) / 1e12
-                also.append({"kernel": k2, "bound": "mfma", "achieved": round(a2, 1), "unit": "TFLOP/s",
-                             "frac": round(a2 / PEAK_TFLOPS[args.dtype], 4), **extra})
+                also.append({**mfma_entry(k2, ms2, n2, fl2, nb2, chip2), **extra})
             elif nb2:
                 a2 = nb2 / (ms2 * 1e-3) / 1e9
                 also.append({"kernel": k2, "bound": "hbm", "achieved": round(a2, 1), "unit": "GB/s", "frac": round(a2 / 8000.0, 4), **extra})
         result["roofline"]["next_kernels"] = also
-        result["roofline"]["plan_kernel_ms_per_step"] = round(total / 2, 3)
+        result["roofline"]["plan_kernel_ms_per_step"] = round(sum(v[0] for v in agg.values()) / 2, 3)
+        result["roofline"]["plan_chip_ms_per_step"] = round(total / 2, 3)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log("per-kernel profile done; timing the CPU oracle baseline")

@@ -114,11 +114,13 @@ class Launch:
     """One C-ABI call.  `flops` is the ALGORITHMIC work of the launch (2*MACs of the convolution it
     implements, real channel counts) when it is a GEMM-shaped kernel, else 0; `tag` names the kernel
     variant the launcher dispatches to (for per-kernel roofline accounting in bench.py)."""
-    __slots__ = ("name", "args", "flops", "tag", "bytes", "side")
+    __slots__ = ("name", "args", "flops", "tag", "bytes", "side", "cus")
 
-    def __init__(self, name, *args, flops=0, tag="", nbytes=0, side=False):
+    def __init__(self, name, *args, flops=0, tag="", nbytes=0, side=False, cus=1.0):
         self.name, self.args, self.flops, self.tag, self.bytes = name, args, flops, tag, nbytes
         self.side = side          # True: may run on the plan's side stream (weight-gradient launches)
+        self.cus = cus            # share of the chip's CUs the launch is sized for (1.0 unless its workgroups own CUs by design:
+                                  # the eight-wave weight gradient runs on 128 of 256; bench.py's chip-time accounting)
 
 
 class Plan:
@@ -596,7 +598,7 @@ class Builder:
                 ws = self.ws_bytes(splits * Co * k * k * x.C * 4)
                 self.bwd.append(Launch("mi355_conv2d_wgrad", x, dy, ws, splits, x.N, x.H, x.W, x.C, x.ld, Ho, Wo, Co, dy.ld,
                                        k, k, s, p, 1 if up else 0, self.code, flops=flops, nbytes=nbytes, side=True,
-                                       tag=self.wgrad_tag(Co, x.C, k, s, Ho, Wo, x.N, p)))
+                                       tag=self.wgrad_tag(Co, x.C, k, s, Ho, Wo, x.N, p), cus=self.wgrad_cus(x.N, Ho, Wo, x.C, Co, k, s, p, splits)))
                 ref, beta = self.pgrad(conv.weight)
                 self.bwd.append(Launch("mi355_conv2d_wgrad_reduce", ws, splits, ref, Co, x.C, conv.in_channels, k, k, 0, beta, side=True))
             if conv.bias is not None and conv.bias.requires_grad and not bias_done:
@@ -637,7 +639,7 @@ class Builder:
             ops += list(pend[i]) if i < n else [None, None]
         self.bwd.append(Launch("mi355_conv2d_wgrad_multi", *ops, n, ws, splits, x0.N, x0.H, x0.W, x0.C, x0.ld, Ho, Wo, Co,
                                pend[0][1].ld, 1 if up else 0, self.code, flops=flops * n, nbytes=nbytes * n, side=True,
-                               tag=self.wgrad_tag(Co, x0.C, k, 1, Ho, Wo, x0.N, 1)))
+                               tag=self.wgrad_tag(Co, x0.C, k, 1, Ho, Wo, x0.N, 1), cus=self.wgrad_cus(x0.N, Ho, Wo, x0.C, Co, k, 1, 1, splits)))
         ref, beta = self.pgrad(conv.weight)
         self.bwd.append(Launch("mi355_conv2d_wgrad_reduce", ws, splits, ref, Co, x0.C, conv.in_channels, k, k, 0, beta, side=True))
 
@@ -666,6 +668,13 @@ class Builder:
         if v:
             return "wgrad3x3_halo8_kernel" if v >= 3 else "wgrad3x3_halo_kernel"
         return f"conv_wgrad_kernel<{t},{128 if co % 128 == 0 else 64},{128 if ci % 128 == 0 else 64}>"
+
+    def wgrad_cus(self, N, Ho, Wo, ci, co, k, s, p, splits):
+        """Share of the 256 CUs a weight-gradient launch is sized for: the eight-wave nine-tap kernel's workgroups own their CU
+        (512 threads x 256 registers), and its grid — (Co / 64) x (Ci / 64) tiles x splits — is a deliberate share of the chip."""
+        if self.esz != 2 or lib.mi355_conv2d_wgrad_variant(N, Ho, Wo, k, k, s, p, self.code) < 3:
+            return 1.0
+        return min(1.0, -(-co // 64) * -(-ci // 64) * splits / 256.0)
 
     def bias_grad_from(self, dy, bias):
         nb = lib.mi355_rowreduce_blocks(dy.M)

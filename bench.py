@@ -179,32 +179,50 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(hw, bs=8, steps=3):
+# model of the GPU line -> (oracle net, state keyword arguments, segmentation?, CPU batch): the CPU leg runs the SAME model as the
+# GPU line on a batch small enough for ~10-30 s of host work (BASELINE.md section 3 states the reduced batches)
+CPU_CONFIGS = {
+    "AttentionUNet": ("AttentionUNet", {}, True, 8),          # the reference's own segmentation batch size (trainer.py:160)
+    "R2AttU_Net": ("R2AttU_Net", {}, True, 4),
+    "R2U_Net": ("R2U_Net", {}, True, 4),
+    "ResNetUnet": ("ResNetUnet", {}, True, 8),                # frozen ResNet-50 encoder: only the decoder trains (ResnetUnet.py:60-66)
+    "resnet18": ("ResNet18", {"head_dropout": True}, False, 8),      # BASELINE.json configs[0]: bs 8
+    "resnet50": ("ResNet50", {"head_dropout": True}, False, 8),
+    "vgg16": ("VGG16", {"head_dropout": True}, False, 4),
+    "vgg16_bn": ("VGG16_BN", {"num_classes": 3, "head_dropout": True}, False, 4),
+}
+
+
+def cpu_baseline(model, hw, steps=3):
     """SURVEY.md 8(d) protocol: the reference-equivalent CPU path (oracle/: plain torch fp32 restatement of the reference's
-    train step, helpers.py:320-336) on ALL of this box's host cores (the process's affinity mask), B = 8 (the reference's own
-    segmentation batch size, trainer.py:160; the benchmark's 32 would take ~1 min per step), one warm-up + 3 timed steps,
-    images/s = B / median step time; CPU model and core count reported."""
+    train step, helpers.py:320-336) for the model of the GPU line, on ALL of this box's host cores (the process's affinity
+    mask), a reduced batch (CPU_CONFIGS), one warm-up + 3 timed steps, images/s = B / median step time; CPU model and core
+    count reported."""
     from oracle import nets, train as otrain
+    net, kw, seg, bs = CPU_CONFIGS[model]
     # every core this process is entitled to: affinity mask / cgroup quota, and — the GPU pool's rule for a box that shows the
     # whole host — the 16-core share that comes with each visible GPU (BENCH_CPU_THREADS overrides)
     cores = min(host_cores(), 16 * max(1, torch.cuda.device_count()))
     if os.environ.get("BENCH_CPU_THREADS"):
         cores = max(1, int(os.environ["BENCH_CPU_THREADS"]))
     torch.set_num_threads(cores)
-    sd = nets.default_init_state("AttentionUNet", seed=0)
-    x, y = otrain.synthetic_batch(bs, hw, seed=0)
-    opt = otrain.AdamW(nets.param_keys(sd), 1e-6)
-    otrain.train_step("AttentionUNet", sd, x, y, opt, True)
+    sd = nets.default_init_state(net, seed=0, **kw)
+    x, y = otrain.synthetic_batch(bs, hw, seed=0, classes=None if seg else 3)
+    keys = nets.param_keys(sd)
+    trainable = [k for k in keys if not k.startswith("encoder")] if net == "ResNetUnet" else None
+    opt = otrain.AdamW(trainable or keys, 1e-6)
+    otrain.train_step(net, sd, x, y, opt, seg, trainable)
     times = []
     for _ in range(steps):
         t0 = time.time()
-        otrain.train_step("AttentionUNet", sd, x, y, opt, True)
+        otrain.train_step(net, sd, x, y, opt, seg, trainable)
         times.append(time.time() - t0)
     dt = sorted(times)[len(times) // 2]
     return {"value": round(bs / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
             "cpu_model": cpu_model_name(),
-            "sample": f"AttentionUNet {hw}x{hw} fp32 train step (fwd+BCE+bwd+clip+AdamW), B={bs} (reference's seg batch size; "
-                      f"the GPU line runs B=32), 1 warm-up + {steps} timed steps, B / median step time",
+            "sample": f"{net} {hw}x{hw} fp32 train step (fwd+{'BCE' if seg else 'CE'}+bwd+clip+AdamW"
+                      f"{', frozen encoder' if trainable else ''}), B={bs} (the GPU line runs its own batch size), "
+                      f"1 warm-up + {steps} timed steps, B / median step time",
             "step_seconds": [round(t, 3) for t in times]}
 
 
@@ -420,7 +438,8 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log("per-kernel profile done; timing the CPU oracle baseline")
-        result["cpu_baseline"] = cpu_baseline(args.size, 8, 3)
+        if args.model in CPU_CONFIGS:
+            result["cpu_baseline"] = cpu_baseline(args.model, args.size)
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(result) + "\n").encode())

@@ -114,10 +114,11 @@ def cosine_lr(base_lr, epoch_done, t_max, eta_min=0.0):
 # ----------------------------------------------------------------------------
 # one optimisation step + the segmentation training loop
 # ----------------------------------------------------------------------------
-def forward_backward(net, sd, x, y, seg=True, **net_kw):
-    """zero_grad -> forward(train) -> loss -> backward.  Returns (loss, logits, grads)."""
+def forward_backward(net, sd, x, y, seg=True, trainable=None, **net_kw):
+    """zero_grad -> forward(train) -> loss -> backward.  Returns (loss, logits, grads).  ``trainable``: the parameter keys that
+    require a gradient (default: all) — ResNetUnet(freeze=True) keeps its encoder frozen (ResnetUnet.py:60-66)."""
     fn = nets.NETS[net]
-    pk = nets.param_keys(sd)
+    pk = nets.param_keys(sd) if trainable is None else list(trainable)
     for k in pk:
         sd[k].requires_grad_(True)
         sd[k].grad = None
@@ -133,9 +134,9 @@ def forward_backward(net, sd, x, y, seg=True, **net_kw):
     return float(loss.detach()), out.detach(), grads
 
 
-def train_step(net, sd, x, y, opt: AdamW, seg=True, **net_kw):
+def train_step(net, sd, x, y, opt: AdamW, seg=True, trainable=None, **net_kw):
     """helpers.py:320-336 on CPU (autocast and GradScaler are disabled no-ops there)."""
-    loss, out, grads = forward_backward(net, sd, x, y, seg, **net_kw)
+    loss, out, grads = forward_backward(net, sd, x, y, seg, trainable, **net_kw)
     gnorm = clip_grad_norm(list(grads.values()), 1.0)
     with torch.no_grad():
         opt.step(sd, grads)

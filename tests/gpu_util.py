@@ -45,6 +45,12 @@ def q(x, dtype):
     return x.to(dtype).float()
 
 
+def _fma32(a, b, c):
+    """fmaf(a, b, c) of fp32 tensors: the product is exact in fp64, the sum is rounded once to fp64 and once to fp32 — the same
+    value as the fused operation except in double-rounding ties, and always the same SIGN (what a ReLU mask needs)."""
+    return (a.double() * b.double() + c.double()).float()
+
+
 def gpu_kinks(plan):
     """ReLU masks (NCHW bool) and max-pool arg-max indices (torch layout) of the forward the plan just ran — the decisions the
     GPU actually took, read back from the plan's activation buffers (Plan.acts), for replay inside the oracle (oracle.nets.Kinks)."""
@@ -53,15 +59,18 @@ def gpu_kinks(plan):
     for a in plan.acts:
         if a[0] == "relu":
             relu.append((a[1].torch_view().float() > 0).permute(0, 3, 1, 2).contiguous().cpu())
-        elif a[0] == "relu_pre":                  # recurrent block: only x + relu(.) is stored; the mask is that of scale * y + shift
+        elif a[0] == "relu_pre":                  # recurrent block: only x + relu(.) is stored; the mask is that of fmaf(y, scale, shift)
             y, sc, sh = a[1], a[2], a[3]
-            v = torch.addcmul(sh[: y.C].view(1, 1, 1, -1), y.torch_view().float(), sc[: y.C].view(1, 1, 1, -1))
+            v = _fma32(y.torch_view().float(), sc[: y.C].view(1, 1, 1, -1), sh[: y.C].view(1, 1, 1, -1))
             relu.append((v > 0).permute(0, 3, 1, 2).contiguous().cpu())
         elif a[0] == "relu_pre2":                 # attention gate: relu(bn(g1) + bn(x1)) is never stored (mi355_gate_psi_fwd)
+            # the kernels' own chain (gate.hip): sh = shift_g + shift_x, f = fmaf(g1, scale_g, sh), f = fmaf(x1, scale_x, f) — an
+            # un-fused a * b + c puts a few of the 10^7 near-zero elements on the other side, and a replay with THOSE masks is 2-4e-3
+            # off in the gate's gradients at the 32 x 32 level (measured at the benchmark shape)
             g1, sg, tg, x1, sx, tx = a[1:]
             c = g1.C
-            v = torch.addcmul((tg[:c] + tx[:c]).view(1, 1, 1, -1), g1.torch_view().float(), sg[:c].view(1, 1, 1, -1))
-            v = torch.addcmul(v, x1.torch_view().float(), sx[:c].view(1, 1, 1, -1))
+            v = _fma32(g1.torch_view().float(), sg[:c].view(1, 1, 1, -1), (tg[:c] + tx[:c]).view(1, 1, 1, -1))
+            v = _fma32(x1.torch_view().float(), sx[:c].view(1, 1, 1, -1), v)
             relu.append((v > 0).permute(0, 3, 1, 2).contiguous().cpu())
         elif a[0] == "relu_v":                    # ReLU behind a Linear of a classifier head: fp32 [B, F]
             y = a[1]

@@ -299,16 +299,6 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pp128_kernel(const ConvArgs 
 #endif
   T* __restrict__ out = reinterpret_cast<T*>(a.out);
   struct alignas(8) Pack4 { T v[4]; };
-  // The epilogue's lane geometry comes from the hardware's lane counter, not from the prologue's registers: nothing lane-derived
-  // has to stay live across the main loop for it (the allocator spilled exactly that value to scratch: one store in the prologue,
-  // reloads — each a compiler-placed wait — in every epilogue variant).
-  auto lane_now = []() __attribute__((always_inline)) {      // (asm volatile: never merged with an earlier copy, so never kept)
-    int l;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-    return l;
-  };
-  const int lane_e = lane_now();
-  const int l16e = lane_e & 15, c4e = lane_e >> 4, tide = wave * 64 + lane_e;
   unsigned char* const ctile = lds + half * Cfg::C_BYTES;
   float* const red = reinterpret_cast<float*>(lds + 2 * Cfg::C_BYTES);      // [half][wm][2][BN]
   auto finish = [&](auto relu_tag, auto stats_tag) __attribute__((always_inline)) {
@@ -317,13 +307,13 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pp128_kernel(const ConvArgs 
     f32x4 bias4[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-      bias4[nb] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n0 + wn * WTN + nb * 16 + 4 * c4e) : f32x4{0.f, 0.f, 0.f, 0.f};
+      bias4[nb] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n0 + wn * WTN + nb * 16 + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < 2; ++j) { sm[nb][j] = f32x2{0.f, 0.f}; sq[nb][j] = f32x2{0.f, 0.f}; }
     }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
-      const int row = mb * TW + wm * 16 + l16e;                 // pixel of this lane inside its half tile (mb = tile row)
+      const int row = mb * TW + wm * 16 + l16;                 // pixel of this lane inside its half tile (mb = tile row)
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         Pack4 pk;
@@ -340,7 +330,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pp128_kernel(const ConvArgs 
             sq[nb][j] += v * v;
           }
         }
-        *reinterpret_cast<Pack4*>(ctile + row * C_PITCH + (wn * WTN + nb * 16 + 4 * c4e) * 2) = pk;
+        *reinterpret_cast<Pack4*>(ctile + row * C_PITCH + (wn * WTN + nb * 16 + 4 * c4) * 2) = pk;
       }
     }
     if constexpr (STATS) {
@@ -349,9 +339,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pp128_kernel(const ConvArgs 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float s1 = row16_sum(sm[nb][r >> 1][r & 1]), s2 = row16_sum(sq[nb][r >> 1][r & 1]);
-          if ((lane_now() & 15) == 0) {
-            red[((half * 2 + wm) * 2 + 0) * BN + wn * WTN + nb * 16 + 4 * c4e + r] = s1;
-            red[((half * 2 + wm) * 2 + 1) * BN + wn * WTN + nb * 16 + 4 * c4e + r] = s2;
+          if (l16 == 0) {
+            red[((half * 2 + wm) * 2 + 0) * BN + wn * WTN + nb * 16 + 4 * c4 + r] = s1;
+            red[((half * 2 + wm) * 2 + 1) * BN + wn * WTN + nb * 16 + 4 * c4 + r] = s2;
           }
         }
     }
@@ -365,8 +355,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pp128_kernel(const ConvArgs 
   };
   finish_any();
   __syncthreads();
-  if (a.stats && tide < 2 * BN) {
-    const int q = tide / BN, c = tide - q * BN;
+  if (a.stats && tid < 2 * BN) {
+    const int q = tid / BN, c = tid - q * BN;
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) v += red[(w * 2 + q) * BN + c];
@@ -376,7 +366,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pp128_kernel(const ConvArgs 
   constexpr int BM = TH * TW;                 // 512 tile pixels: tile row r lives in C tile r / 256 at row r % 256
   if (a.pool2) {
     const int Ho2 = a.Ho >> 1, Wo2 = a.Wo >> 1;
-    for (int id = tide; id < (BM / 4) * CPRC; id += 512) {
+    for (int id = tid; id < (BM / 4) * CPRC; id += 512) {
       const int g = id / CPRC, c = id - g * CPRC;
       const int gy = g / (TW / 2), gx = g - gy * (TW / 2);
       float sum[EPC];
@@ -405,7 +395,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pp128_kernel(const ConvArgs 
     }
     return;
   }
-  for (int id = tide; id < BM * CPRC; id += 512) {
+  for (int id = tid; id < BM * CPRC; id += 512) {
     const int row = id / CPRC, c = id - row * CPRC;
     const int py = row / TW, px = row - py * TW;
     T* p = out + ((size_t)(n * a.Ho + y0 + py) * a.Wo + x0 + px) * a.ldo + n0 + c * EPC;

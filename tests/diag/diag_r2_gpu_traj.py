@@ -1,6 +1,8 @@
 """GPU counterpart of diag_r2_chaos.py: the protocol of tests/test_gpu_train_bf16.py[R2AttU_Net] on the HIP path in fp32 and bf16,
 Dice on the 32 held-out images and last-batch loss after 8 / 12 / 20 / 32 / 48 steps (no oracle: its numbers are in
-diag_r2_chaos.py's output).   python tests/diag/diag_r2_gpu_traj.py [marks...]"""
+diag_r2_chaos.py's output).   python tests/diag/diag_r2_gpu_traj.py [marks...]
+R2_DECAY_AT=k R2_LR2=x: the learning rate drops to x after k steps (the conditioned criterion of round 4: the trajectory is allowed to
+settle before Dice is read); R2_HELD=n: Dice over n held-out images, in chunks of 32 (train-mode BatchNorm per chunk)."""
 import os
 import sys
 
@@ -25,7 +27,17 @@ def dice(logit, m):
 marks = [int(a) for a in sys.argv[1:]] or [8, 12, 20, 32, 48]
 hw, b, lr = 64, 4, 1e-3
 batches = [task(b, hw, s) for s in range(4)]
-xv, mv = task(32, hw, 99)
+held = int(os.environ.get("R2_HELD", "32"))
+decay_at, lr2 = int(os.environ.get("R2_DECAY_AT", "0")), float(os.environ.get("R2_LR2", "1e-4"))
+held_sets = [task(32, hw, 99 + c) for c in range(held // 32)]
+
+
+def held_dice(m):
+    num = den = 0.0
+    for xv, mv in held_sets:
+        p = (torch.sigmoid(m(xv.cuda()).float().cpu()) > 0.5).double(); t = (mv > 0.5).double()
+        num += float(2 * (p * t).sum()); den += float(p.sum() + t.sum())
+    return (num + 1e-7) / (den + 1e-7)
 sd0 = nets.default_init_state("R2AttU_Net", seed=0)
 for dtype in (torch.float32, torch.bfloat16):
     m = get_seg_model("r2attunet"); m.load_state_dict(sd0); m.compute_dtype = dtype
@@ -33,8 +45,11 @@ for dtype in (torch.float32, torch.bfloat16):
     out = []
     for i in range(max(marks)):
         x, y = batches[i % 4]
+        if decay_at and i == decay_at:
+            for g in opt.param_groups:
+                g["lr"] = lr2
         opt.zero_grad(); loss = crit(m(x.cuda()), y.cuda()); loss.backward(); moptim.clip_grad_norm_(m.parameters(), 1.0); opt.step()
         if i + 1 in marks:
             with torch.no_grad():
-                out.append((i + 1, dice(m(xv.cuda()).float().cpu(), mv), float(loss.detach())))
+                out.append((i + 1, held_dice(m), float(loss.detach())))
     print(f"HIP {str(dtype):15s} " + "  ".join(f"step {s}: Dice {d:.5f} loss {l:.5f}" for s, d, l in out), flush=True)

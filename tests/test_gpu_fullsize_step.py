@@ -6,14 +6,14 @@ the HIP path: forward in train mode (M = 2 097 152 rows through the statistic fo
 the whole backward (split weight gradients, every BatchNorm backward pass at its 1 024-workgroup cap, the fused gate / head /
 pool passes).  The oracle evaluates the same step in fp32 on the host cores with the ReLU masks and max-pool decisions the
 GPU ACTUALLY took replayed (oracle.nets.Kinks; without the replay any two fp32 evaluations differ by ~1e-3 per flipped mask,
-tests/test_gpu_kinks.py).  Asserted, all relative to the tensor's maximum: loss, the train-mode logits of the first and last
-image and every BatchNorm running_mean / running_var within 1e-3 (measured: 6e-5 and 5e-7), and the parameter gradients —
-ALL 138 / 156 tensors: median <= 2e-4, 95 % of them within 1e-3 (north star: "within 1e-3 relative fp32"), none beyond 1e-2.
-Measured (printed by the test): median 6e-5 / 9e-5, maximum 4.5e-3 (att5.W_x.0.weight) / 2.7e-3 — the yardstick here is an
-fp32 evaluation itself (oneDNN's fp32 accumulation over up to 2 million pixels per weight; fp64 costs 12x the time and would
-take this test from 25 s to 5 min): the sharp statement, every tensor within 1e-3 of an fp64 oracle on the same masks, is
-tests/test_gpu_kinks.py's at 4 x 128 x 128 — what THIS test adds is the benchmark shape, where an indexing error in a fold,
-a split or a fused pass would show up as an O(1) difference in whole tensors, not as 4e-3 in one.  Reference: /root/reference/models/segmentation_models/AttentionUNet.py:86-121,
+tests/test_gpu_kinks.py; the read-back mirrors the kernels' own fmaf chains, gpu_util._fma32 — with masks from an un-fused
+a * b + c a handful of the 10^7 gate elements land on the other side of zero and the 32 x 32 gate's gradients are 2-4e-3 off).
+Asserted, all relative to the tensor's maximum and all within 1e-3 (north star: "within 1e-3 relative fp32"): loss, the
+train-mode logits of the first and last image, every BatchNorm running_mean / running_var, and EVERY parameter-gradient tensor
+(the conv biases in front of a BatchNorm, whose gradient is mathematically zero, are exact zeros on the HIP path).  Measured
+(printed by the test): logits 6e-5 / 2e-5, buffers 1e-7 / 5e-7, gradients median 1e-5 / 8e-6, maximum 4.9e-4 (att5.psi.1.weight)
+/ 8.7e-5 — against an fp32 oracle, whose own rounding over up to 2 million pixels per weight is part of those numbers.
+Reference: /root/reference/models/segmentation_models/AttentionUNet.py:86-121,
 R2AttU_Net.py:119-158, utils/helpers.py:320-336."""
 import os
 import sys
@@ -114,5 +114,4 @@ def test_full_size_fp32_train_step_matches_the_cpu_oracle(name):
     print(f"\n[{name} {bs}x{hw}x{hw} fp32 step vs CPU oracle, {len(e)} gradient tensors + {n_zero} identically zero biases] loss {got['loss']:.6f} vs {ref_loss:.6f}; logits "
           f"{e_first:.1e} / {e_last:.1e}; BN buffers max {e_buf[worst_b]:.1e} ({worst_b}); gradients median {np.median(e):.1e} "
           f"max {e.max():.1e} ({worst}), {int((e > 1e-3).sum())} beyond 1e-3; GPU + read-back {t1 - t0:.0f} s, oracle {t2 - t1:.0f} s")
-    assert np.median(e) <= 2e-4 and np.mean(e <= 1e-3) >= 0.95 and e.max() <= 1e-2, \
-        (worst, e_g[worst], float(np.median(e)), sorted(e_g.items(), key=lambda kv: -kv[1])[:6])
+    assert np.median(e) <= 1e-4 and e.max() <= 1e-3, (worst, e_g[worst], float(np.median(e)), sorted(e_g.items(), key=lambda kv: -kv[1])[:6])

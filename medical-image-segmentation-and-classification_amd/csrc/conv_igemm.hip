@@ -596,7 +596,8 @@ static IgemmVariant resolve_variant(IgemmVariant v, int N, int Ho, int Wo, int C
   const int cus = device_cus();
   const long long grid = (long long)N * (Ho / 16) * (Wo / 32) * (Co / 128);
   const long long rounds = (grid + cus - 1) / cus;
-  return grid * 5 >= rounds * cus * 4 ? IG_HALO_PP128 : IG_HALO_8x32;          // >= 80 % of the last round filled
+  static const int fill = getenv("MI355_PP128_FILL") ? atoi(getenv("MI355_PP128_FILL")) : 80;      // (A/B switch, percent)
+  return grid * 100 >= rounds * cus * fill ? IG_HALO_PP128 : IG_HALO_8x32;     // >= 80 % of the last round filled
 }
 
 static bool halo_family(IgemmVariant v) {

@@ -4,6 +4,7 @@ and therefore on every gradient by ~1e-3, whatever the implementation.  With the
 fp64 evaluation both compute the same smooth function and agree to rounding accuracy — the basis of the sharp whole-model
 gradient checks of tests/test_gpu_kinks.py."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import nets
@@ -71,3 +72,34 @@ def test_r2attunet_training_trajectory_is_chaotic_on_the_cpu_alone():
     print("R2AttU_Net CPU control, step 8: Dice", dict(zip(runs, dice.round(5))), "loss", dict(zip(runs, loss.round(5))))
     assert dice.min() > 0.95                                    # every run learns the task
     assert dice.max() - dice.min() > 5e-4, dice                 # ... and they have visibly parted (measured 2.7e-3 among these three)
+
+
+def test_trajectory_fixture_learning_rate_control():
+    """CPU-only control for the learning rate of the recurrent nets' trajectory fixtures (tests/golden/train_traj_R2AttU_Net.npz:
+    the reference's own train(), helpers.py:231-412, 3 epochs x 2 batches at 64 x 64, lr 1e-5; round 3 had generated it at 1e-4 /
+    32 x 32 first and the HIP run missed its validation loss by 1.5 %).  The SAME protocol is evaluated twice on the oracle — all
+    cores and ONE thread, i.e. the same function with fp32 sums in another order — at lr 1e-4 and at lr 1e-5.  Adam turns the
+    SIGN of noise-level gradients into full +-lr steps, so the two evaluations part in proportion to lr: measured here (8 cores),
+    epoch-1 validation loss 3.4e-3 apart at 1e-4 (23.275 / 23.196) and 6.4e-4 apart at 1e-5 (22.2707 / 22.2565); the bottleneck's
+    running mean likewise.  Asserted: the 1e-5 pair agrees to the 2e-3 that tests/test_oracle_pins.py::test_train_trajectory_seg
+    allows between the oracle and the reference's log, and the 1e-4 pair is at least twice as far apart."""
+    name, hw = "R2AttU_Net", 64
+    b = [otrain.synthetic_batch(4, hw, seed=s) for s in (0, 1, 2)]
+    n_threads = torch.get_num_threads()
+    gaps = {}
+    try:
+        for lr in (1e-4, 1e-5):
+            vals = []
+            for threads in (n_threads, 1):
+                torch.set_num_threads(threads)
+                sd = nets.closed_form_state(name)
+                _, hist = otrain.train_seg(name, sd, b[:2], b[2:], 1, lr)
+                vals.append(hist[0][1])                  # epoch-1 validation loss
+            gaps[lr] = abs(vals[0] - vals[1]) / abs(vals[0])
+    finally:
+        torch.set_num_threads(n_threads)
+    print(f"R2AttU_Net trajectory control ({n_threads} threads vs 1): relative gap of the epoch-1 validation loss:", gaps)
+    if n_threads == 1:
+        pytest.skip("one core: the two evaluations are the same arithmetic")
+    assert gaps[1e-5] <= 2e-3, gaps
+    assert gaps[1e-4] >= 2 * gaps[1e-5], gaps

@@ -354,16 +354,25 @@ extern "C" int mi355_bn_act_windows(const void* x, int ldx, const float* scale, 
 // default policy finds part of them in the memory-side cache (end of round 3: -0.13 ms per step against streaming reads — round 2
 // had measured the opposite on a plan with more passes between the two; the apply passes' own reads stay streaming).
 // MI355_BN_REDUCE_NT=1 restores the streaming reads (A/B).
-static inline int bn_reduce_keeps() {
+// MI355_BN_KEEP_MB: operand pairs larger than this (MB) cannot be found again in the 256 MB memory-side cache by the pass behind
+// them — they are read with streaming loads whatever the switches say (0 = no limit).
+static inline long long bn_keep_limit() {
+  static const long long mb = getenv("MI355_BN_KEEP_MB") ? atoll(getenv("MI355_BN_KEEP_MB")) : 0;
+  return mb > 0 ? mb * 1000000ll : 0;
+}
+static inline int bn_reduce_keeps(long long bytes = 0) {
   static const int nt = getenv("MI355_BN_REDUCE_NT") ? atoi(getenv("MI355_BN_REDUCE_NT")) : 0;
+  if (bn_keep_limit() && bytes > bn_keep_limit()) return 0;
   return nt ? 0 : 1;
 }
 
 // ... and of the APPLY passes' reads: the default policy as well since the end of round 3 (-0.13 ms per step; round 2 had measured
 // streaming reads ahead by 0.02).  MI355_BN_APPLY_NT=1 restores them (A/B).  The forward apply pass keeps its streaming read of the
 // raw convolution output (default policy there: +0.09 ms).
-static inline int bn_apply_keeps() {
+static inline int bn_apply_keeps(long long bytes = 0) {
   static const int nt = getenv("MI355_BN_APPLY_NT") ? atoi(getenv("MI355_BN_APPLY_NT")) : 0;
+  static const int lim = getenv("MI355_BN_KEEP_APPLY") ? atoi(getenv("MI355_BN_KEEP_APPLY")) : 0;      // (the size rule for the apply pass too)
+  if (lim && bn_keep_limit() && bytes > bn_keep_limit()) return 0;
   return nt ? 0 : 1;
 }
 
@@ -424,7 +433,7 @@ extern "C" int mi355_bn_bwd_reduce(const void* dy, int lddy, const void* y, int 
   MI355_CHECK_ARG(dy && x && mean && invstd && partial && (!act || y || (mscale && mshift)), "bn_bwd_reduce: null pointer");
   return dispatch_dtype(dtype, "bn_bwd_reduce", [&](auto tag) {
     using T = decltype(tag);
-    const int keep = bn_reduce_keeps();
+    const int keep = bn_reduce_keeps(2ll * M * C * (long long)sizeof(T));
     BnBwdReduceOp<T> op{(const T*)dy, lddy, (const T*)y, ldy, (const T*)x, ldx, mean, invstd, mscale, mshift, act, keep};
     return rowred_launch<T>(op, M, C, partial, (hipStream_t)s);
   });
@@ -538,7 +547,7 @@ extern "C" int mi355_bn_bwd_apply(const void* dy, int lddy, const void* y, int l
                                   float* dbias_partial, long long M, int C, int act, int dtype, mi355_stream_t s) {
   MI355_CHECK_ARG(dy && x && gamma && mean && invstd && sums && dx && (!act || y || (mscale && mshift)), "bn_bwd_apply: null pointer");
   const float invM = (float)(1.0 / (double)M);
-  const int apply_keep = bn_apply_keeps();
+  const int apply_keep = bn_apply_keeps(2ll * M * C * (dtype_is_2byte(dtype) ? 2 : 4));
   return dispatch_dtype(dtype, "bn_bwd_apply", [&](auto tag) {
     using T = decltype(tag);
     BnBwdApplyOp<T> op{(const T*)dy, lddy, (const T*)y, ldy, (const T*)x, ldx, gamma, mean, invstd,
@@ -694,7 +703,7 @@ extern "C" int mi355_bn_bwd_reduce_pool2(const void* dy, int lddy, const void* d
     using T = decltype(tag);
     auto run = [&](auto op) {
       fill_pool2<T>(op, dy, lddy, dp, lddp, x, ldx, mean, invstd, mscale, mshift, W, C);
-      op.keep = bn_reduce_keeps();
+      op.keep = bn_reduce_keeps(2ll * N * H * W * C * (long long)sizeof(T));
       return rowred_launch<T>(op, (long long)N * H * W, C, partial, (hipStream_t)s);
     };
     return dy ? run(BnBwdReducePool2Op<T, true>{}) : run(BnBwdReducePool2Op<T, false>{});
@@ -711,7 +720,7 @@ extern "C" int mi355_bn_bwd_apply_pool2(const void* dy, int lddy, const void* dp
     using T = decltype(tag);
     auto run = [&](auto op) {
       fill_pool2<T>(op, dy, lddy, dp, lddp, x, ldx, mean, invstd, mscale, mshift, W, C);
-      op.keep = bn_apply_keeps();
+      op.keep = bn_apply_keeps(2ll * M * C * (long long)sizeof(T));
       op.gamma = gamma; op.sums = sums; op.dx = (T*)dx; op.lddx = lddx; op.invM = (float)(1.0 / (double)M); op.C = C;
       return rowred_launch<T>(op, M, C, nullptr, (hipStream_t)s);
     };

@@ -1399,6 +1399,27 @@ class Builder:
         for r in reversed(self._rules):
             r()
         assert not self._pending_wgrad, "a shared convolution's weight gradient is still waiting for an application's backward"
+        # The side launches BEHIND the last main-stream launch of the backward (the first layer's weight gradient and its reduce)
+        # have nothing left to overlap with: on the side stream they only put a cross-queue join (~50 us until the main queue sees the
+        # side queue's signal, production trace profiles/r04d_trace_step_timeline.txt) in front of the optimiser.  They run on the
+        # main stream; the join then finds the side stream long finished.  MI355_TAIL_ON_MAIN=0 switches it off (A/B).
+        # (the slab workspace is side-stream property, tests/test_plan_cpu.py::test_slab_workspace_is_owned_by_one_stream: the tail
+        #  gets a slab of its own, sized from its reduce launch)
+        if os.environ.get("MI355_TAIL_ON_MAIN", "1") != "0":
+            tail = []
+            for l in reversed(self.bwd):
+                if not l.side:
+                    break
+                tail.append(l)
+            need = 0
+            for l in tail:
+                if l.name == "mi355_conv2d_wgrad_reduce":       # (ws, splits, dw, Co, Ci, Ci_real, KH, KW, transposed, beta)
+                    need = max(need, int(l.args[1]) * int(l.args[3]) * int(l.args[4]) * int(l.args[6]) * int(l.args[7]) * 4)
+            own = self._alloc(need, torch.uint8) if need else None
+            if all(not isinstance(a, Ws) or (a.kind == "bytes" and own is not None) for l in tail for a in l.args):
+                for l in tail:
+                    l.side = False
+                    l.args = tuple(own if isinstance(a, Ws) else a for a in l.args)
         # resolve _WsOff into (tensor, byte offset) late-bound pairs
         plan = Plan(self)
         for lst in (plan.pre, plan.fwd, plan.bwd):

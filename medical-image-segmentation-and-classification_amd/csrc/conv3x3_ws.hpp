@@ -155,17 +155,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(const ConvArgs a, co
   // per tile: 512 rows instead of 8192 at 256 x 256 x 32 images (no pre-fold launch, a 16 x smaller fold)
   f32x2 wsm[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}}, wsq[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
   for (int sp = sp_begin; sp < sp_end; ++sp) {
+    // tiles in COLUMN order (ty fastest): consecutive tiles of a workgroup's range are vertical neighbours, so the two halo rows a
+    // tile shares with its predecessor were fetched one tile ago and are still in the XCD's L2 (-DWS_ROW_ORDER: tx fastest, A/B)
     int t = sp;
+#ifdef WS_ROW_ORDER
     const int tx = t % TXN; t /= TXN;
     const int ty = t % TYN;
     const int n = t / TYN;
+#else
+    const int ty = t % TYN; t /= TYN;
+    const int tx = t % TXN;
+    const int n = t / TXN;
+#endif
     const int y0 = ty * TH, x0 = tx * TW;
     // descriptor + lane offsets of a tile's patch
     auto patch_of = [&](int sp2, bufdesc_t& desc, unsigned (&off)[P_IT]) __attribute__((always_inline)) {
       int t2 = sp2;
+#ifdef WS_ROW_ORDER
       const int tx2 = t2 % TXN; t2 /= TXN;
       const int ty2 = t2 % TYN;
       const int n2 = t2 / TYN;
+#else
+      const int ty2 = t2 % TYN; t2 /= TYN;
+      const int tx2 = t2 % TXN;
+      const int n2 = t2 / TXN;
+#endif
       const int yy0 = ty2 * TH - 1, xx0 = tx2 * TW - 1;                  // logical coordinates of the patch origin
       const long long org = ((long long)n2 * a.Hi * a.Wi + (long long)(yy0 >> a.up) * a.Wi + (xx0 >> a.up)) * a.ldi;   // (floor shifts)
       desc = make_buf(in + org);

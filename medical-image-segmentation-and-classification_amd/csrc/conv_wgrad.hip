@@ -256,7 +256,11 @@ extern "C" int mi355_conv2d_wgrad_splits(int N, int Ho, int Wo, int Ci, int Co, 
     // partial slabs are written and reduced.  Step: 64 / 96 / 112 / 128 / 144 / 160 / 192 / 256 workgroups = 17.7 / 16.2 / 16.1 /
     // 15.40 / 15.6 / 15.65 / 15.9 / 16.3 ms against 15.74 for the four-wave kernel (profiles/r04a_wgs_sweep8.txt).
     static const int wgs_env = getenv("MI355_WGRAD_WGS") ? atoi(getenv("MI355_WGRAD_WGS")) : 0;      // (A/B switch)
-    const int wgs = wgs_env > 0 ? wgs_env : (mode >= 3 ? 128 : 256);
+    int wgs = wgs_env > 0 ? wgs_env : (mode >= 3 ? 128 : 256);
+    // (A/B: another grid for the eight-wave kernel on images of at most MI355_WGRAD_DEEP_H rows)
+    static const int deep_wgs = getenv("MI355_WGRAD_WGS_DEEP") ? atoi(getenv("MI355_WGRAD_WGS_DEEP")) : 0;
+    static const int deep_h = getenv("MI355_WGRAD_DEEP_H") ? atoi(getenv("MI355_WGRAD_DEEP_H")) : 64;
+    if (mode >= 3 && deep_wgs > 0 && Ho <= deep_h) wgs = deep_wgs;
     long long s = wgs / tiles;
     if (s > items) s = items;
     const long long slab = (long long)Co * 9 * Ci * 4;

@@ -69,13 +69,20 @@ def main():
         raise SystemExit("the MI355X path needs a GPU (no CPU fallback)")
     # one process per GPU under torch.distributed.run: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the launcher
     world, rank, local_rank = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # (MI355_DP_BACKEND=gloo: ranks may share a GPU — a rehearsal of the launcher path on a one-GPU box, tests/test_gpu_dp_train.py;
+    #  RCCL wants a device per rank)
+    backend = os.environ.get("MI355_DP_BACKEND", "nccl")
+    local_dev = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+    device = torch.device("cuda", local_dev)
     split_gen = None                                      # (single process: unseeded, like the reference's random_split)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
         seed = [int(torch.randint(0, 2 ** 31 - 1, (1,)))]
         dist.broadcast_object_list(seed, src=0)          # every rank must cut the SAME 80/20 split
         split_gen = torch.Generator().manual_seed(seed[0])

@@ -168,3 +168,23 @@ def test_train_world2_matches_single_process_emulation(tmp_path):
         assert np.abs(v.astype(np.float64) - r).max() <= 1e-6 * max(np.abs(r).max(), 1e-30) + 1e-12, k
     saved = torch.load(os.path.join(save_dir, "AttentionUNet_best_loss.pt"), map_location="cpu")
     assert set(saved) == set(sd0)
+
+
+def test_trainer_script_under_the_launcher_two_ranks(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 utils/trainer.py ...` end to end (the command INTEGRATION.md gives, with
+    MI355_DP_BACKEND=gloo because both ranks share this box's one GPU): the script joins the group, both ranks cut the same 80 / 20
+    split, train() shards the batches, rank 0 alone prints the epoch lines and the summary and writes the checkpoint."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "medical-image-segmentation-and-classification_amd", "utils", "trainer.py")
+    env = dict(os.environ, MI355_DP_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), script, "--task", "seg", "--model", "attentionunet", "--epochs", "2", "--samples", "20",
+           "--size", "32", "--save-dir", str(tmp_path / "w")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("[attentionunet] Ep")]
+    assert len(lines) == 2, r.stdout                       # one line per epoch: rank 1 printed nothing
+    assert r.stdout.count("===== SUMMARY =====") == 1 and "best val loss" in r.stdout
+    assert os.listdir(str(tmp_path / "w" / "segmentation_models")) == ["attentionunet_best_loss.pt"]

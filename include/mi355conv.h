@@ -99,7 +99,9 @@ int mi355_conv2d_igemm(const void* in, const void* wk, const float* bias, void* 
  * workgroups empty; mi355_conv2d_igemm_stat_rows, which knows N, follows the launcher); 7 the weight-stationary persistent
  * kernel (3x3/s1/p1, Ci == 64, Co % 64 == 0, image divisible by 8 x 32: the 64-channel layers of every U-Net level,
  * AttentionUNet.py:62-63,82, R2AttU_Net.py:36-39; the launcher falls back to variant 2 below two tiles per workgroup); 8 its
- * Ci == 128 instantiation (4 x 32-pixel tiles: AttentionUNet.py:65-66,78-79,81). */
+ * Ci == 128 instantiation (4 x 32-pixel tiles: AttentionUNet.py:65-66,78-79,81); 9 the padding-free GEMM kernel (conv_gemm256_kernel:
+ * 1x1 at stride 1 / 2, 2x2 / stride 2, ConvTranspose2d(2, 2) as four pointwise phases; Ci % 64 == 0, Co % 128 == 0, whole 256-row
+ * tiles, at least 128 of them — the ResNet-50 encoder's 1x1 convolutions and ResnetUnet.py:21,51's transposed convolutions). */
 int mi355_conv2d_igemm_variant(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int mul, int kmul, int off,
                                int div, int up, int dtype);
 /* ... and the variant the launcher actually runs for a batch of N images (the batch-dependent fall-backs applied). */

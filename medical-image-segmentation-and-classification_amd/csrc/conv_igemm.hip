@@ -509,6 +509,7 @@ static int launch_dma(const ConvArgs& a, hipStream_t s) {
 #include "conv3x3_halo_pp128.hpp"
 #include "conv3x3_ws.hpp"
 #include "conv1x1_stream.hpp"
+#include "conv_gemm256.hpp"
 
 template <typename T, int BN, int BK>
 static int launch(const ConvArgs& a, hipStream_t s) {
@@ -525,7 +526,7 @@ static int launch_bn(const ConvArgs& a, hipStream_t s) {
   return launch<T, 32, BK>(a, s);
 }
 
-enum IgemmVariant { IG_GENERIC = 0, IG_DMA, IG_HALO_8x32, IG_HALO_16x16, IG_STREAM1x1, IG_HALO_PP, IG_HALO_PP128, IG_WS64, IG_WS128 };
+enum IgemmVariant { IG_GENERIC = 0, IG_DMA, IG_HALO_8x32, IG_HALO_16x16, IG_STREAM1x1, IG_HALO_PP, IG_HALO_PP128, IG_WS64, IG_WS128, IG_GEMM256 };
 
 // ONE place that decides which kernel serves a shape (also used by the statistics-row query).
 static IgemmVariant pick_variant(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int mul, int kmul, int off,
@@ -563,6 +564,10 @@ static IgemmVariant pick_variant(int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
   // narrow pointwise convolutions (and their data gradients): register-resident weights, streaming pixels
   if (KH == 1 && KW == 1 && mul == 1 && div == 1 && !up && off == 0 && Ho == Hi && Wo == Wi && stream1x1_shape(Ci, Co))
     return IG_STREAM1x1;
+  // padding-free convolutions as plain GEMMs on 256 x 128 tiles (conv_gemm256.hpp): 1x1, 2x2 / stride 2, ConvTranspose2d(2, 2) phases;
+  // batch-dependent conditions (row count, grid size) in final_variant.  MI355_GEMM256=0 switches it off (A/B)
+  static const int use_gemm256 = getenv("MI355_GEMM256") ? atoi(getenv("MI355_GEMM256")) : 1;
+  if (use_gemm256 && gemm256_mode(256, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up)) return IG_GEMM256;
   if (Co % 64 != 0 && Ci % 64 != 0) return IG_GENERIC;      // 32-wide tile with a 32-deep slab: too few DMA pieces per wave
   return IG_DMA;
 }
@@ -606,7 +611,12 @@ static bool halo_family(IgemmVariant v) {
 static bool image_fits_descriptor(int Hi, int Wi, int ldi, int esz) { return (long long)Hi * Wi * ldi * esz < (1ll << 31); }
 static IgemmVariant final_variant(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int mul, int kmul, int off,
                                   int div, int up, int dtype) {
-  const IgemmVariant v = resolve_variant(pick_variant(Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up, dtype), N, Ho, Wo, Co);
+  IgemmVariant v = resolve_variant(pick_variant(Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up, dtype), N, Ho, Wo, Co);
+  if (v == IG_GEMM256) {      // whole 256-row tiles only, and enough of them to fill the chip once (one workgroup per CU)
+    static const long long min_tiles = getenv("MI355_GEMM256_MIN_TILES") ? atoll(getenv("MI355_GEMM256_MIN_TILES")) : 128;
+    const int gm = gemm256_mode(N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up);
+    if (!gm || gemm256_tiles(gm, N, Hi, Wi, Ho, Wo, Co) < min_tiles) v = IG_DMA;
+  }
   return halo_family(v) && !image_fits_descriptor(Hi, Wi, Ci, 2) ? IG_DMA : v;
 }
 
@@ -631,6 +641,8 @@ extern "C" int mi355_conv2d_igemm_stat_rows(int N, int Hi, int Wi, int Ci, int H
     case IG_HALO_16x16: return N * (Ho / 16) * (Wo / 16);
     case IG_DMA: return ceil_div((long long)N * Ho * Wo, 128);
     case IG_STREAM1x1: return stream1x1_grid((long long)N * Ho * Wo);
+    case IG_GEMM256:         // one row per 256-pixel tile; the ConvTranspose2d phases have no statistics epilogue
+      return gemm256_mode(N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up) == 1 ? (int)((long long)N * Ho * Wo / 256) : 0;
     default: return 0;       // generic kernel: no fused statistics, run mi355_bn_stats
   }
 }
@@ -692,6 +704,7 @@ extern "C" int mi355_conv2d_igemm(const void* in, const void* wk, const float* b
         case IG_HALO_8x32: return launch_halo_rw<T, 8, 32>(a, st);
         case IG_HALO_16x16: return launch_halo_rw<T, 16, 16>(a, st);
         case IG_STREAM1x1: return launch_stream1x1<T>(a, st);
+        case IG_GEMM256: return launch_gemm256<T>(a, gemm256_mode(N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up), st);
         case IG_DMA:
           // measured on MI355X (AttentionUNet shapes): the 2-deep BK=64 ring (2 workgroups/CU) wins for 128-wide tiles,
           // the 3-deep BK=32 ring (3-4 workgroups/CU) for 64-wide tiles and for Ci % 64 != 0

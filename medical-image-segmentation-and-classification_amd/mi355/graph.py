@@ -659,7 +659,8 @@ class Builder:
                 return "conv_igemm_dma_kernel<128,64,2>" if k64 else "conv_igemm_dma_kernel<128,32,3>"
             return "conv_igemm_dma_kernel<64,32,3>" if bn == 64 else "conv_igemm_dma_kernel<32,64,3>"
         return {2: "conv3x3_halo_rw_kernel<8,32>", 3: "conv3x3_halo_rw_kernel<16,16>", 4: f"conv1x1_stream_kernel<{ci},{co}>",
-                5: "conv3x3_halo_pp_kernel", 6: "conv3x3_halo_pp128_kernel", 7: "conv3x3_ws_kernel<64,8>", 8: "conv3x3_ws_kernel<128,4>"}[v]
+                5: "conv3x3_halo_pp_kernel", 6: "conv3x3_halo_pp128_kernel", 7: "conv3x3_ws_kernel<64,8>", 8: "conv3x3_ws_kernel<128,4>",
+                9: "conv_gemm256_kernel"}[v]
 
     def wgrad_tag(self, co, ci, k=1, s=1, Ho=0, Wo=0, N=0, p=None):
         """Name of the kernel mi355_conv2d_wgrad runs: the launcher's own choice (mi355_conv2d_wgrad_variant)."""
@@ -920,8 +921,11 @@ class Builder:
         wf, wb = self.packs(mod, Ci, transposed=True)
         Ho, Wo = x.H * s, x.W * s
         y = out if out is not None else self.new_tensor(x.N, Ho, Wo, Co)
+        flops = 2 * x.N * x.H * x.W * Ci * Co * k * k
+        nbytes = (x.N * x.H * x.W * Ci + x.N * Ho * Wo * Co + Ci * Co * k * k) * self.esz
         self.fwd.append(Launch("mi355_conv2d_igemm", x, wf, mod.bias, y, x.N, x.H, x.W, Ci, x.ld, Ho, Wo, Co, y.ld, k, k,
-                               1, -1, 0, s, 0, 0, None, self.code))
+                               1, -1, 0, s, 0, 0, None, self.code, flops=flops, nbytes=nbytes,
+                               tag=self.igemm_tag(x.N, x.H, x.W, Ci, Ho, Wo, Co, k, 1, -1, 0, s, 0)))
         y.needs_grad = x.needs_grad or mod.weight.requires_grad
 
         def rule():
@@ -943,7 +947,8 @@ class Builder:
                 acc = self.acc_flag(x)
                 xg = self.grad_of(x)
                 self.bwd.append(Launch("mi355_conv2d_igemm", dy, wb, None, xg, x.N, Ho, Wo, Co, dy.ld, x.H, x.W, Ci, xg.ld,
-                                       k, k, s, 1, 0, 1, 0, acc, None, self.code))
+                                       k, k, s, 1, 0, 1, 0, acc, None, self.code, flops=flops, nbytes=nbytes,
+                                       tag=self.igemm_tag(x.N, Ho, Wo, Co, x.H, x.W, Ci, k, s, 1, 0, 1, 0)))
         self.rule(rule)
         return y
 

@@ -147,6 +147,62 @@ def test_conv_transpose_2x2(dtype):
     assert rel_err(from_nhwc(y), ref) < TOL[dtype]
 
 
+GEMM_CASES = [  # kind, N, Ci, Hi, Wi, Co          (>= 128 tiles of 256 rows x 128 columns each: the launcher's threshold)
+    ("1x1", 8, 128, 32, 32, 512), ("1x1", 2, 512, 64, 64, 256), ("1x1s2", 8, 256, 64, 64, 512), ("2x2s2", 8, 64, 64, 64, 512),
+    ("convT", 4, 256, 16, 16, 1024), ("convT", 16, 64, 32, 32, 128),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", GEMM_CASES)
+def test_padding_free_convolutions_as_gemms(case, dtype):
+    """conv_gemm256_kernel (csrc/conv_gemm256.hpp, variant 9): 1x1 convolutions at stride 1 and 2 (ResNet-50 bottlenecks and
+    shortcuts, the attention gates' wide W_g / W_x), 2x2 / stride-2 convolutions (the data gradient of ConvTranspose2d(2, 2)) and
+    ConvTranspose2d(2, 2) itself as four pointwise phases (ResnetUnet.py:21,51) against torch — plain, with bias + ReLU + fused
+    BatchNorm statistics into a channel slice of a wider buffer, and accumulating."""
+    kind, n, ci, h, w_, co = case
+    code = DTYPE_CODE[dtype]
+    g = torch.Generator().manual_seed(ci + co + h)
+    x = torch.randn(n, ci, h, w_, generator=g)
+    b = torch.randn(co, generator=g)
+    if kind == "convT":
+        w = torch.randn(ci, co, 2, 2, generator=g) / (ci ** 0.5)
+        ref = F.conv_transpose2d(q(x, dtype), q(w, dtype), b, stride=2)
+        wf, _ = pack_w(w, dtype, transposed=True)
+        k, geo = 2, (1, -1, 0, 2)                       # mul, kmul, off, div
+    else:
+        k, s = {"1x1": (1, 1), "1x1s2": (1, 2), "2x2s2": (2, 2)}[kind]
+        w = torch.randn(co, ci, k, k, generator=g) / ((ci * k * k) ** 0.5)
+        ref = F.conv2d(q(x, dtype), q(w, dtype), b, stride=s)
+        wf, _ = pack_w(w, dtype)
+        geo = (s, 1, 0, 1)
+    ho, wo = ref.shape[2], ref.shape[3]
+    assert lib.mi355_conv2d_igemm_variant_n(n, h, w_, ci, ho, wo, co, k, k, *geo, 0, code) == 9
+    xd = to_nhwc(x, dtype)
+    y = torch.full((n, ho, wo, co), float("nan"), dtype=dtype, device=DEV)
+    lib.mi355_conv2d_igemm(xd, wf, b.to(DEV), y, n, h, w_, ci, ci, ho, wo, co, co, k, k, *geo, 0, 0, None, code)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(y), ref) < TOL[dtype]
+    # accumulate (a data gradient joining an existing one)
+    y2 = y.clone()
+    lib.mi355_conv2d_igemm(xd, wf, b.to(DEV), y2, n, h, w_, ci, ci, ho, wo, co, co, k, k, *geo, 0, 1, None, code)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(y2), 2 * ref) < 2 * TOL[dtype]
+    # bias + ReLU (+ fused statistics where the variant has them) into a channel slice of a wider buffer
+    rows = lib.mi355_conv2d_igemm_stat_rows(n, h, w_, ci, ho, wo, co, k, k, *geo, 0, code)
+    assert rows == (0 if kind == "convT" else n * ho * wo // 256)
+    part = torch.full((max(rows, 1) * 2 * co,), float("nan"), device=DEV)
+    wide = torch.zeros(n, ho, wo, co + 32, dtype=dtype, device=DEV)
+    lib.mi355_conv2d_igemm(xd, wf, b.to(DEV), wide.data_ptr() + 32 * 2, n, h, w_, ci, ci, ho, wo, co, co + 32, k, k, *geo, 0, 2,
+                           part if rows else None, code)
+    torch.cuda.synchronize()
+    got = wide[..., 32:].float().cpu().permute(0, 3, 1, 2)
+    assert rel_err(got, F.relu(ref)) < TOL[dtype] and float(wide[..., :32].abs().max()) == 0.0
+    if rows:
+        st = part.view(rows, 2, co).sum(0).cpu()
+        assert rel_err(st[0], got.double().sum((0, 2, 3)).float()) < 1e-3 and rel_err(st[1], (got.double() ** 2).sum((0, 2, 3)).float()) < 1e-3
+
+
 def test_bad_args_raise():
     x = torch.zeros(1, 4, 4, 24, device=DEV)
     with pytest.raises(RuntimeError, match="Ci"):

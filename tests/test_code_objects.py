@@ -54,6 +54,7 @@ HOT = [  # (mangled-name pattern, what it is)
     (r"conv3x3_halo_rw_kernel", "four-wave halo 3x3"),
     (r"conv1x1_stream_kernel", "streaming pointwise convolution"),
     (r"conv_igemm_dma_kernel", "LDS-DMA ring implicit GEMM"),
+    (r"conv_gemm256_kernel", "padding-free convolutions as 256 x 128-tile GEMMs"),
     (r"rowred_kernel|rowmap_kernel|bn_act_pool2_kernel", "BatchNorm passes"),
     (r"gate_psi_fwd|gate_bn_bwd|gate_mul", "attention-gate passes"),
     (r"adamw|bce_logits|sumsq", "loss / optimiser"),

@@ -148,7 +148,7 @@ def test_conv_transpose_2x2(dtype):
 
 
 GEMM_CASES = [  # kind, N, Ci, Hi, Wi, Co          (>= 128 tiles of 256 rows x 128 columns each: the launcher's threshold)
-    ("1x1", 8, 128, 32, 32, 512), ("1x1", 2, 512, 64, 64, 256), ("1x1s2", 8, 256, 64, 64, 512), ("2x2s2", 8, 64, 64, 64, 512),
+    ("1x1", 8, 128, 32, 32, 512), ("1x1", 4, 512, 64, 64, 256), ("1x1s2", 8, 256, 64, 64, 512), ("2x2s2", 8, 64, 64, 64, 512),
     ("convT", 4, 256, 16, 16, 1024), ("convT", 16, 64, 32, 32, 128),
 ]
 

@@ -58,43 +58,48 @@ extern "C" int mi355_pack_input_nchw(const float* x, void* y, int N, int C, int 
 // stem is a POINTWISE convolution with K = 27 -> 32 on the same parameter memory ([Co][3][3][3] read as [Co][27]): the same bytes
 // written as the padded tensor, one ninth of the matrix work, and the streaming 1 x 1 kernels forward and for the weight gradient.
 template <typename T>
-__global__ void pack_im2col3_kernel(const float* __restrict__ x, T* __restrict__ y, int C, int H, int W, long long NHW, int ld) {
+__global__ void pack_im2col3_kernel(const float* __restrict__ x, T* __restrict__ y, int C, int H, int W, int ld) {
   constexpr int EPC = 16 / (int)sizeof(T);
   constexpr int CP = 32 / EPC;
-  // One thread per pixel: the 9 C plane reads of a wave are 64 consecutive pixels each (coalesced; the 25 MB of input are re-read
-  // nine times from the caches), its 64 bytes leave as CP 16-byte stores — a wave instruction covers every CP-th 16-byte chunk of
-  // 4 KiB, the CP of them whole lines.  (A thread per 16-byte chunk with the pixel fastest left every 64-byte record to four
-  // workgroups far apart in time: 116 us for the 134 MB of a 32 x 256 x 256 batch; chunk fastest: 86 us; this form: 79 us; the
-  // same records staged through LDS so that every store instruction writes one contiguous KiB: 80 us — the stores are not the limit.)
-  const long long HW = (long long)H * W;
-  for (long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x; pix < NHW; pix += (long long)gridDim.x * blockDim.x) {
-    const long long n = pix / HW, hw = pix - n * HW;
-    const int h = (int)(hw / W), w = (int)(hw - (long long)h * W);
-    float v[32];
+  // One thread per pixel, one workgroup row per image row (blockIdx.y = n * H + h: the row / image split is scalar arithmetic, no
+  // per-thread 64-bit divisions): the 9 C plane reads of a wave are 64 consecutive pixels each (coalesced; the 25 MB of input are
+  // re-read nine times from the caches), its 64 bytes leave as CP 16-byte stores.  History, 134 MB of a 32 x 256 x 256 batch: a
+  // thread per 16-byte chunk with the pixel fastest (every 64-byte record left to four workgroups far apart in time) 116 us;
+  // chunk fastest 86 us; a thread per pixel on a flat grid (two 64-bit divisions per pixel) 79 us; the same records staged
+  // through LDS so that every store instruction writes one contiguous KiB 80 us — the stores were not the limit; this grid 74 us;
+  // unconditional clamped loads (below) 56 us.
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= W) return;
+  const int n = blockIdx.y / H, h = blockIdx.y - n * H;
+  const float* __restrict__ xn = x + (size_t)n * C * H * W;
+  float v[32];
 #pragma unroll
-    for (int k = 0; k < 32; ++k) {
-      const int c = k / 9, t = k - c * 9, hh = h + t / 3 - 1, ww = w + t % 3 - 1;
-      const bool in = c < C && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
-      v[k] = in ? x[(n * C + c) * HW + (long long)hh * W + ww] : 0.f;
-    }
+  for (int k = 0; k < 32; ++k) {
+    const int c = k / 9, t = k - c * 9, hh = h + t / 3 - 1, ww = w + t % 3 - 1;
+    const bool in = c < C && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+    // unconditional load from a clamped address, the select behind it: a load under a condition is branched around and waited
+    // for before the next one is issued (27 dependent round trips per thread)
+    const int cc = c < C ? c : C - 1, hc = min(max(hh, 0), H - 1), wc = min(max(ww, 0), W - 1);
+    const float val = xn[((size_t)cc * H + hc) * W + wc];
+    v[k] = in ? val : 0.f;
+  }
+  T* __restrict__ yp = y + ((size_t)blockIdx.y * W + w) * ld;
 #pragma unroll
-    for (int ck = 0; ck < CP; ++ck) {
-      Vec16<T> o;
+  for (int ck = 0; ck < CP; ++ck) {
+    Vec16<T> o;
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) o.v[e] = from_f32<T>(v[ck * EPC + e]);
-      st16<T>(y + pix * ld + ck * EPC, o);
-    }
+    for (int e = 0; e < EPC; ++e) o.v[e] = from_f32<T>(v[ck * EPC + e]);
+    st16<T>(yp + ck * EPC, o);
   }
 }
 
 extern "C" int mi355_pack_input_im2col3(const float* x, void* y, int N, int C, int H, int W, int dtype, mi355_stream_t s) {
   MI355_CHECK_ARG(x && y && C >= 1 && C <= 3 && N > 0, "pack_input_im2col3: bad arguments (C=%d: 9 C must fit 32 channels)", C);
-  const long long NHW = (long long)N * H * W;
+  MI355_CHECK_ARG((long long)N * H <= 0x7fffffffll && H > 0 && W > 0, "pack_input_im2col3: N * H = %lld rows overflow the grid", (long long)N * H);
   return dispatch_dtype(dtype, "pack_input_im2col3", [&](auto tag) {
     using T = decltype(tag);
-    long long blocks = (NHW + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL((pack_im2col3_kernel<T>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, x, (T*)y, C, H, W, NHW, 32);
+    const int bx = W >= 256 ? 256 : (W >= 128 ? 128 : 64);
+    hipLaunchKernelGGL((pack_im2col3_kernel<T>), dim3((W + bx - 1) / bx, N * H), dim3(bx), 0, (hipStream_t)s, x, (T*)y, C, H, W, 32);
     MI355_LAUNCH_CHECK();
     return (int)MI355_OK;
   });

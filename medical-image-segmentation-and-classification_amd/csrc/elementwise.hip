@@ -212,9 +212,23 @@ __global__ __launch_bounds__(256) void pack_weight_batched_kernel(const long lon
     __syncthreads();
     for (int r = wave; r < na; r += 4) {
       const int a = a0 + r;
-      const float* src = w + ((size_t)a * B + b0) * taps;
-      const float f = (oscale && !transposed && a < A) ? oscale[a] : 1.f;
-      for (int e = lane; e < len; e += 64) tile[r * PITCH + e] = (a < A && e < nbv) ? src[e] * f : 0.f;
+      // unconditional loads from clamped indices, the select behind them (a load under a condition is branched around and waited
+      // for before the next one is issued: five dependent round trips per row)
+      const int ac = a < A ? a : A - 1, bc = b0 < B ? b0 : B - 1;
+      const float* src = w + ((size_t)ac * B + bc) * taps;
+      const float f = (oscale && !transposed) ? oscale[ac] : 1.f;
+      constexpr int NE = (ROWMAX + 63) / 64;
+      float val[NE];
+#pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        const int e = lane + 64 * i;
+        val[i] = src[e < nbv ? e : 0];
+      }
+#pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        const int e = lane + 64 * i;
+        if (e < len) tile[r * PITCH + e] = (a < A && e < nbv) ? val[i] * f : 0.f;
+      }
     }
     __syncthreads();
     // 2-byte packs leave as 16-byte stores (eight consecutive inner elements per lane, the index arithmetic once per eight)

@@ -23,12 +23,17 @@ __global__ void pack_nchw_kernel(const float* __restrict__ x, T* __restrict__ y,
     const int ck = (int)(i % cp);
     const long long pix = i / cp;
     const long long n = pix / HW, hw = pix - n * HW;
-    Vec16<T> o;
+    // every plane read is issued from a clamped channel and masked afterwards: a load under `c < C` is branched around and
+    // waited for one at a time (eight dependent round trips per chunk)
+    float val[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
       const int c = ck * EPC + e;
-      o.v[e] = from_f32<T>(c < C ? x[(n * C + c) * HW + hw] : 0.f);
+      val[e] = x[(n * C + (c < C ? c : C - 1)) * HW + hw];
     }
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) o.v[e] = from_f32<T>(ck * EPC + e < C ? val[e] : 0.f);
     st16<T>(y + pix * ld + ck * EPC, o);
   }
 }

@@ -373,6 +373,8 @@ def main():
                        "final_loss": round(final_loss, 5), "host_issue_ms_per_step": round(issue_one_ms, 3),
                        "plan_replay": "C (mi355_plan_run)" if os.environ.get("MI355_PLAN_C", "1") != "0" else "python loop"},
         }
+        if dp is not None:                        # fp32 = parity mode (default); MI355_DP_BUCKET_DTYPE=bf16: two-byte buckets on the wire
+            result["config"]["grad_bucket_dtype"] = {None: "fp32", torch.bfloat16: "bf16", torch.float16: "fp16"}[dp.wire_dtype]
         if args.model == "AttentionUNet":         # (SURVEY.md 8d gives the per-image FLOPs of this model only)
             step_tflops = TRAIN_GFLOP_PER_IMG * (args.size / 256) ** 2 * value / world / 1e3
             result["config"]["step_mfma_frac"] = round(step_tflops / PEAK_TFLOPS[args.dtype], 4)

@@ -421,6 +421,11 @@ int mi355_comm_init(int rank, int world, const void* id128);
 int mi355_comm_world(void);
 int mi355_allreduce_bucket(void* ptr, long long count, int dtype, mi355_stream_t s);
 int mi355_comm_destroy(void);
+/* bf16 / fp16 buckets (SURVEY.md 8e "bf16 (perf) buckets"; the reference has no gradient exchange at all, utils/helpers.py:329-335):
+ * wire[i] = round(g[i]) for a bucket of n gradients, and back (g[i] = wire[i]) behind the all-reduce of the staging buffer;
+ * g 16-byte aligned, wire 8-byte aligned (a bucket starts on a multiple of four gradients), dtype = MI355_BF16 / MI355_F16. */
+int mi355_grads_to_wire(const float* g, void* wire, long long n, int dtype, mi355_stream_t s);
+int mi355_grads_from_wire(const void* wire, float* g, long long n, int dtype, mi355_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -376,6 +376,14 @@ static inline int bn_apply_keeps(long long bytes = 0) {
   return nt ? 0 : 1;
 }
 
+// The apply pass re-reads what the reduce pass just read.  Walking the rows from the END meets the reduce pass's most recent lines
+// first: when the pair of tensors is larger than the 256 MB memory-side cache a second forward sweep finds nothing (each line was
+// evicted before its turn comes again), a backward sweep finds whatever the cache still holds.  MI355_BN_APPLY_REV (A/B).
+static inline int bn_apply_reversed() {
+  static const int rev = getenv("MI355_BN_APPLY_REV") ? atoi(getenv("MI355_BN_APPLY_REV")) : 0;
+  return rev;
+}
+
 template <typename T> struct BnBwdReduceOp {
   static constexpr int NQ = 2;
   static constexpr bool WRITES = false;
@@ -393,7 +401,10 @@ template <typename T> struct BnBwdReduceOp {
       mt[e] = (act && !y) ? mshift[c0 + e] : 0.f;
     }
   }
-  static constexpr int FETCH_ROWS = 4;
+  #ifndef BN_RED_FETCH
+#define BN_RED_FETCH 4
+#endif
+  static constexpr int FETCH_ROWS = BN_RED_FETCH;
   struct In { Vec16<T> g, xv, yv; };
   __device__ In fetch(size_t row, int c0) const {
     In in;
@@ -483,6 +494,7 @@ template <typename T> struct BnBwdApplyOp {
   const float* gamma; const float* mean; const float* invstd; const float* mscale; const float* mshift; const float* sums;
   T* dx; int lddx; T* dres; int lddres; T* dpost; int lddpost; int post_acc;
   float invM; int C; int act; int keep;
+  long long last;      // >= 0: the pass walks the rows from the END (row r of the sweep is tensor row last - r), see bn_apply_reversed
   float mu[EPC], is[EPC], k0[EPC], k1[EPC], gi[EPC], ms[EPC], mt[EPC];
   __device__ void load_cols(int c0) {
 #pragma unroll
@@ -500,6 +512,7 @@ template <typename T> struct BnBwdApplyOp {
   struct In { Vec16<T> g, xv, yv, pv; };
   __device__ In fetch(size_t row, int c0) const {
     In in;
+    if (last >= 0) row = (size_t)last - row;
     if (keep) {
       in.g = ld16<T>(dy + row * lddy + c0);
       in.xv = ld16<T>(x + row * ldx + c0);
@@ -512,6 +525,7 @@ template <typename T> struct BnBwdApplyOp {
     return in;
   }
   __device__ void finish(const In& in, size_t row, int c0, Acc (&acc)[NQ][EPC]) const {
+    if (last >= 0) row = (size_t)last - row;
     if (dpost) {      // gradient of an operand added after the activation: the incoming gradient itself
       Vec16<T> pg = in.g;
       if (post_acc) {
@@ -551,7 +565,8 @@ extern "C" int mi355_bn_bwd_apply(const void* dy, int lddy, const void* y, int l
   return dispatch_dtype(dtype, "bn_bwd_apply", [&](auto tag) {
     using T = decltype(tag);
     BnBwdApplyOp<T> op{(const T*)dy, lddy, (const T*)y, ldy, (const T*)x, ldx, gamma, mean, invstd,
-                       mscale, mshift, sums, (T*)dx, lddx, (T*)dres, lddres, (T*)dpost, lddpost, post_acc, invM, C, act, apply_keep};
+                       mscale, mshift, sums, (T*)dx, lddx, (T*)dres, lddres, (T*)dpost, lddpost, post_acc, invM, C, act, apply_keep,
+                       bn_apply_reversed() ? M - 1 : -1ll};
     return rowred_launch<T>(op, M, C, dbias_partial, (hipStream_t)s);
   });
 }

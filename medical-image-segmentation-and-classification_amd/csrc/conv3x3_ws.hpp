@@ -227,6 +227,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(const ConvArgs a, co
       auto rd = [&](auto v_tag) __attribute__((always_inline)) {
         constexpr int v = decltype(v_tag)::value;                       // visit = pw * PH + pr
         constexpr int pw = v / PH, pr = v % PH;
+#ifdef WS_T_NOSHIFTREAD                                                  // timing-only build: the shifted columns reuse stale fragments (a third of the LDS reads)
+        if constexpr (pw > 0) return;
+#endif
 #pragma unroll
         for (int xb = 0; xb < XB; ++xb)
           fr[v % FRD][xb] = *reinterpret_cast<const bf16x8*>(pa + ((fa[pw] ^ ((pr & 1) << 5)) + pr * ROWB + xb * 16 * PIXB));

@@ -594,7 +594,8 @@ static IgemmVariant resolve_variant(IgemmVariant v, int N, int Ho, int Wo, int C
     // (the 128-channel instantiation loads twice the weights per workgroup for tiles half as tall: measured per layer it wins
     //  from 16 tiles per workgroup up — 128² x 128 -> 128 / 256, 256² x 128 -> 64: +3 ... +10 % — and loses 1-6 % at 8 —
     //  64² x 128 -> 256, 128² x 128 -> 64, batch-16 layers — so its threshold is 12 tiles per workgroup = 24 x CUs)
-    if (S >= 8 && S * (Co / 64) >= min_tiles * (v == IG_WS128 ? 6 : 1)) return v;
+    static const int mult128 = getenv("MI355_WS128_TILE_MULT") ? atoi(getenv("MI355_WS128_TILE_MULT")) : 6;      // (A/B switch)
+    if (S >= 8 && S * (Co / 64) >= min_tiles * (v == IG_WS128 ? mult128 : 1)) return v;
     return Ho % 8 == 0 ? IG_HALO_8x32 : (Ho % 16 == 0 && Wo % 16 == 0 ? IG_HALO_16x16 : IG_DMA);
   }
   if (v != IG_HALO_PP128) return v;

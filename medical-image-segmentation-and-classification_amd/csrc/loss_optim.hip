@@ -214,6 +214,71 @@ extern "C" int mi355_fill_f32(float* p, float v, long long n, mi355_stream_t s) 
   return MI355_OK;
 }
 
+// ---- gradient buckets on the wire ("fp32 (parity) or bf16 (perf) buckets") ----------------------------------------
+// A bucket of the flat fp32 gradient buffer is rounded into a 2-byte staging buffer, summed over the ranks there, and widened back
+// in place of the local gradients.  Four gradients per thread and trip: one 16-byte access on the fp32 side, 8 bytes of wire (a
+// bucket starts on a parameter boundary = a multiple of four floats, mi355/engine.py ALIGN).
+template <typename T> struct alignas(8) Wire4 { T v[4]; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void grads_to_wire_kernel(const float* __restrict__ g, T* __restrict__ w, long long n) {
+  const long long n4 = n / 4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(g + 4 * i);
+    Wire4<T> o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o.v[e] = from_f32<T>(a[e]);
+    *reinterpret_cast<Wire4<T>*>(w + 4 * i) = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) w[4 * n4 + threadIdx.x] = from_f32<T>(g[4 * n4 + threadIdx.x]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void grads_from_wire_kernel(const T* __restrict__ w, float* __restrict__ g, long long n) {
+  const long long n4 = n / 4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const Wire4<T> v = *reinterpret_cast<const Wire4<T>*>(w + 4 * i);
+    f32x4 a;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] = to_f32<T>(v.v[e]);
+    *reinterpret_cast<f32x4*>(g + 4 * i) = a;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) g[4 * n4 + threadIdx.x] = to_f32<T>(w[4 * n4 + threadIdx.x]);
+}
+
+static int wire_blocks(long long n) {
+  long long blocks = (n / 4 + 255) / 256;
+  return (int)(blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks));
+}
+
+extern "C" int mi355_grads_to_wire(const float* g, void* wire, long long n, int dtype, mi355_stream_t s) {
+  if (n == 0) return MI355_OK;      // (an empty bucket has no storage to point at)
+  MI355_CHECK_ARG(g && wire && n >= 0 && ((uintptr_t)g % 16 == 0) && ((uintptr_t)wire % 8 == 0) && dtype_is_2byte(dtype),
+                  "grads_to_wire: gradients 16-byte aligned, wire 8-byte aligned, 2-byte wire dtype expected (dtype=%d)", dtype);
+  return dispatch_dtype(dtype, "grads_to_wire", [&](auto tag) {
+    using T = decltype(tag);
+    if constexpr (sizeof(T) == 2) {
+      hipLaunchKernelGGL((grads_to_wire_kernel<T>), dim3(wire_blocks(n)), dim3(256), 0, (hipStream_t)s, g, (T*)wire, n);
+      MI355_LAUNCH_CHECK();
+    }
+    return (int)MI355_OK;
+  });
+}
+
+extern "C" int mi355_grads_from_wire(const void* wire, float* g, long long n, int dtype, mi355_stream_t s) {
+  if (n == 0) return MI355_OK;      // (an empty bucket has no storage to point at)
+  MI355_CHECK_ARG(g && wire && n >= 0 && ((uintptr_t)g % 16 == 0) && ((uintptr_t)wire % 8 == 0) && dtype_is_2byte(dtype),
+                  "grads_from_wire: gradients 16-byte aligned, wire 8-byte aligned, 2-byte wire dtype expected (dtype=%d)", dtype);
+  return dispatch_dtype(dtype, "grads_from_wire", [&](auto tag) {
+    using T = decltype(tag);
+    if constexpr (sizeof(T) == 2) {
+      hipLaunchKernelGGL((grads_from_wire_kernel<T>), dim3(wire_blocks(n)), dim3(256), 0, (hipStream_t)s, (const T*)wire, g, n);
+      MI355_LAUNCH_CHECK();
+    }
+    return (int)MI355_OK;
+  });
+}
+
 // ---- segmentation counters ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void seg_counts_kernel(const float* __restrict__ pr, const float* __restrict__ tg,
                                                          float* __restrict__ counts, long long per, int is_logit, float thr) {

@@ -24,11 +24,18 @@ _NO_COMM = os.environ.get("MI355_DP_NOCOMM") == "1"
 # mi355_allreduce_bucket, csrc/comm.cpp) instead of torch.distributed.all_reduce — same library underneath, no ProcessGroup
 # bookkeeping per call.  torch.distributed stays the default: it is the path the multi-GPU bench has been rehearsed with.
 _NATIVE = os.environ.get("MI355_DP_NATIVE") == "1"
+# MI355_DP_BUCKET_DTYPE=bf16 | fp16: the buckets travel rounded to two bytes (SURVEY.md 8e's "perf" mode: half the xGMI bytes per
+# step; each rank's contribution is rounded once, the ring's partial sums at every hop).  Default fp32 = parity mode: what the
+# data-parallel parity statement and the tests hold.
+_WIRE = {"": None, "fp32": None, "bf16": torch.bfloat16, "fp16": torch.float16}[os.environ.get("MI355_DP_BUCKET_DTYPE", "")]
 
 
 class DataParallel:
-    def __init__(self, net, bucket_mb: float = 32.0, overlap: bool = True, process_group=None, force: bool = False):
+    def __init__(self, net, bucket_mb: float = 32.0, overlap: bool = True, process_group=None, force: bool = False,
+                 bucket_dtype=None):
         self.net = net
+        self.wire_dtype = bucket_dtype if bucket_dtype not in (None, torch.float32) else (_WIRE if bucket_dtype is None else None)
+        self._wire = None                     # 2-byte staging buffer, one element per gradient (allocated on first use)
         self.engine = net.engine
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -140,10 +147,34 @@ class DataParallel:
     def _allreduce(self, lo, hi):
         if _NO_COMM:        # probe: the cost of the bucket schedule itself (MI355_DP_NOCOMM=1), never set in production
             return
+        if self.wire_dtype is not None:
+            return self._allreduce_on_wire(lo, hi)
         if self.native:     # enqueued on the CURRENT stream (the comm stream in the overlapped path)
             lib.mi355_allreduce_bucket(self.engine.flat_g[lo:hi], hi - lo, 0, torch.cuda.current_stream().cuda_stream)
             return
         dist.all_reduce(self.engine.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+
+    def _allreduce_on_wire(self, lo, hi):
+        """The bucket rounded to ``wire_dtype`` in a staging buffer, summed there, widened back over the local gradients — three
+        launches on the CURRENT stream (the comm stream in the overlapped path), in stream order with the collective."""
+        g = self.engine.flat_g
+        if self._wire is None or self._wire.numel() != g.numel() or self._wire.device != g.device:
+            self._wire = torch.empty(g.numel(), dtype=self.wire_dtype, device=g.device)
+        w = self._wire[lo:hi]
+        code = {torch.bfloat16: 1, torch.float16: 2}[self.wire_dtype]
+        if g.is_cuda:
+            s = torch.cuda.current_stream().cuda_stream
+            lib.mi355_grads_to_wire(g[lo:hi], w, hi - lo, code, s)
+        else:               # host rehearsal of the schedule (gloo, no kernels anywhere in it): the same rounding by torch
+            w.copy_(g[lo:hi])
+        if self.native:
+            lib.mi355_allreduce_bucket(w, hi - lo, code, torch.cuda.current_stream().cuda_stream)
+        else:
+            dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.group)
+        if g.is_cuda:
+            lib.mi355_grads_from_wire(w, g[lo:hi], hi - lo, code, torch.cuda.current_stream().cuda_stream)
+        else:
+            g[lo:hi].copy_(w)
 
     def _run_backward(self, plan, stream):
         plan.bind(stream)

@@ -1,4 +1,4 @@
-"""Per-launch timing of every conv launch in the AttentionUNet train plan (HIP events)."""
+"""Per-launch timing of every conv launch in a segmentation model's train plan (HIP events); default AttentionUNet 256^2 bs 32."""
 import sys, os
 R = os.path.join(os.path.dirname(__file__), '..')
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'medical-image-segmentation-and-classification_amd'))
@@ -7,8 +7,10 @@ import bench
 from mi355 import nn as mnn, optim as moptim
 from utils.helpers import get_seg_model
 bs = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-m = get_seg_model("attentionunet"); m.compute_dtype = torch.bfloat16; m = m.cuda().train()
-x, y = bench.make_batch(bs, 256, 0, "cuda")
+name = sys.argv[2] if len(sys.argv) > 2 else "attentionunet"          # conv_layers.py [batch [model [size]]]
+hw = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+m = get_seg_model(name); m.compute_dtype = torch.bfloat16; m = m.cuda().train()
+x, y = bench.make_batch(bs, hw, 0, "cuda")
 crit = mnn.BCEWithLogitsLoss(); opt = moptim.AdamW(m.parameters(), lr=1e-6)
 for _ in range(2):
     out = m(x); crit(out, y).backward()

@@ -17,7 +17,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, bucket_mb, q):
+def _worker(rank, world, port, bucket_mb, q, wire=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -35,7 +35,8 @@ def _worker(rank, world, port, bucket_mb, q):
             for b in net.buffers():
                 b.add_(rank + 1)
         plan = eng.plan_for((2, 3, 32, 32), True, True, torch.float32)
-        dp = DataParallel(net, bucket_mb=bucket_mb, overlap=True)
+        dp = DataParallel(net, bucket_mb=bucket_mb, overlap=True, bucket_dtype=wire)
+        assert dp.wire_dtype == wire
         assert dp.world == world and abs(dp.inv_scale - 1.0 / world) < 1e-12
         # ... are replaced by rank 0's at construction (DDP semantics): replicas apply summed gradients to the SAME weights
         torch.manual_seed(0)
@@ -98,12 +99,14 @@ def _worker(rank, world, port, bucket_mb, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("bucket_mb", [8.0, 1000.0])
-def test_bucketed_allreduce_world2(bucket_mb):
+@pytest.mark.parametrize("bucket_mb,wire", [(8.0, None), (1000.0, None), (8.0, torch.bfloat16)])
+def test_bucketed_allreduce_world2(bucket_mb, wire):
+    """wire=bfloat16: the buckets travel as bf16 staging buffers (SURVEY.md 8e's perf mode); the fake gradients 1.0 / 2.0 and their
+    sum are exact in bf16, so the same assertions hold."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, bucket_mb, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, bucket_mb, q, wire)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]

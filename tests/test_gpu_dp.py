@@ -38,7 +38,7 @@ def _setup():
     return m, shards
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, wire=None):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -46,8 +46,8 @@ def _worker(rank, world, port, q):
         m, shards = _setup()
         from mi355 import nn as mnn, optim as moptim
         from mi355.dp import DataParallel
-        dp = DataParallel(m, bucket_mb=8.0, overlap=True)
-        assert dp.world == 2
+        dp = DataParallel(m, bucket_mb=8.0, overlap=True, bucket_dtype=wire)
+        assert dp.world == 2 and dp.wire_dtype == wire
         opt = moptim.AdamW(m.parameters(), lr=LR, weight_decay=5e-4)
         opt.inv_scale = dp.inv_scale
         crit = mnn.BCEWithLogitsLoss()
@@ -70,11 +70,15 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_dp_world2_matches_single_process_emulation():
+@pytest.mark.parametrize("wire", [None, torch.bfloat16])
+def test_dp_world2_matches_single_process_emulation(wire):
+    """wire=bfloat16: SURVEY.md 8e's perf mode — every bucket rounded to bf16 (mi355_grads_to_wire), summed in bf16, widened back
+    (mi355_grads_from_wire).  The emulation rounds each shard's gradients, adds the two in fp32 and rounds the sum: what a two-rank
+    sum of bf16 values is."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, wire)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=400) for _ in procs), key=lambda r: r[0])
@@ -98,8 +102,9 @@ def test_dp_world2_matches_single_process_emulation():
             x, y = shards[r][s]
             opt.zero_grad(set_to_none=True)
             crit(m(x.to(DEV)), y.to(DEV)).backward()
-            total = eng.flat_g.clone() if total is None else total + eng.flat_g
-        eng.flat_g.copy_(total)
+            g = eng.flat_g.clone() if wire is None else eng.flat_g.to(wire).float()
+            total = g if total is None else total + g
+        eng.flat_g.copy_(total if wire is None else total.to(wire).float())
         moptim.clip_grad_norm_(m.parameters(), 1.0, inv_scale=0.5)
         opt.step()
     torch.cuda.synchronize()
@@ -108,7 +113,7 @@ def test_dp_world2_matches_single_process_emulation():
     assert err <= 1e-6, err
 
 
-def _rccl_worker(port, native, q):
+def _rccl_worker(port, native, q, wire=None):
     """A fresh process: RCCL (torch.distributed backend "nccl") with ONE rank — the production code path of bench.py --gpus N
     (process group, comm stream, bucket schedule, event edges, all-reduce launches on the device) minus the other ranks."""
     import torch.distributed as dist
@@ -125,7 +130,7 @@ def _rccl_worker(port, native, q):
         for tag in ("dp", "plain"):
             m, _ = _setup()
             if tag == "dp":
-                dp = DataParallel(m, bucket_mb=8.0, overlap=True, force=True)
+                dp = DataParallel(m, bucket_mb=8.0, overlap=True, force=True, bucket_dtype=wire)
                 assert dp.native == bool(native) and dp.inv_scale == 1.0
             opt = moptim.AdamW(m.parameters(), lr=LR, weight_decay=5e-4)
             crit = mnn.BCEWithLogitsLoss()
@@ -133,6 +138,8 @@ def _rccl_worker(port, native, q):
                 x, y = shards[0][s_]
                 opt.zero_grad(set_to_none=True)
                 crit(m(x.to(DEV)), y.to(DEV)).backward()
+                if tag == "plain" and wire is not None:          # what one rank's bucket is after the trip over the wire
+                    m.engine.flat_g.copy_(m.engine.flat_g.to(wire).float())
                 moptim.clip_grad_norm_(m.parameters(), 1.0)
                 opt.step()
             torch.cuda.synchronize()
@@ -151,17 +158,18 @@ def _rccl_worker(port, native, q):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("native", [0, 1])
-def test_rccl_code_path_with_one_rank(native):
+@pytest.mark.parametrize("native,wire", [(0, None), (1, None), (0, torch.bfloat16), (1, torch.float16)])
+def test_rccl_code_path_with_one_rank(native, wire):
     """backend="nccl" IS RCCL on ROCm: a spawned child runs init_process_group("nccl", world_size=1), DataParallel(force=True)
     and two optimiser steps.  An all-reduce over one rank is the identity, so the parameters must be BIT-identical to the
     same steps without the data-parallel runner, while everything around it is the multi-GPU path: several buckets, their
     pre-allocated event pairs, the comm stream.  native=1: the same through the library's own RCCL entry points
-    (mi355_comm_init / mi355_allreduce_bucket, MI355_DP_NATIVE=1)."""
+    (mi355_comm_init / mi355_allreduce_bucket, MI355_DP_NATIVE=1).  wire: two-byte buckets (RCCL sums bf16 / fp16 staging buffers);
+    the plain run rounds its gradients the same way before the clip, so the parameters stay bit-identical."""
     import numpy as np
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_rccl_worker, args=(_free_port(), native, q))
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), native, q, wire))
     p.start()
     status, out = q.get(timeout=400)
     p.join(timeout=60)
@@ -169,3 +177,26 @@ def test_rccl_code_path_with_one_rank(native):
     assert out["buckets"] > 1 and out["events"] == out["buckets"]
     assert out["comm_world"] == (1 if native else 0)
     assert np.array_equal(out["dp"], out["plain"])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gradient_wire_kernels_round_like_torch(dtype):
+    """mi355_grads_to_wire / mi355_grads_from_wire on bucket-shaped ranges: a start that is a multiple of four gradients but not of
+    eight (8-byte aligned wire), a length that is not a multiple of four; bit-identical to torch's rounding, neighbours untouched."""
+    _setup()
+    from mi355.lib import lib
+    code = {torch.bfloat16: 1, torch.float16: 2}[dtype]
+    gen = torch.Generator().manual_seed(5)
+    g = (torch.randn(5000, generator=gen) * torch.logspace(-6, 3, 5000)).to(DEV)
+    w = torch.full((5000,), 7.0, dtype=dtype, device=DEV)
+    s = torch.cuda.current_stream().cuda_stream
+    for lo, hi in ((4, 1007), (1012, 1012), (2000, 4999)):
+        lib.mi355_grads_to_wire(g[lo:hi], w[lo:hi], hi - lo, code, s)
+        assert torch.equal(w[lo:hi], g[lo:hi].to(dtype))
+        assert float(w[lo - 1]) == 7.0 and float(w[hi]) == 7.0
+        back = torch.full_like(g, -3.0)
+        lib.mi355_grads_from_wire(w[lo:hi], back[lo:hi], hi - lo, code, s)
+        assert torch.equal(back[lo:hi], g[lo:hi].to(dtype).float())
+        assert float(back[lo - 1]) == -3.0 and float(back[hi]) == -3.0
+    with pytest.raises(RuntimeError):           # a wire pointer that is only 2-byte aligned
+        lib.mi355_grads_to_wire(g[4:100], w[5:101], 96, code, s)

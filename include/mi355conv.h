@@ -207,6 +207,15 @@ int mi355_bn_bwd_apply(const void* dy, int lddy, const void* y, int ldy, const v
                        const float* mshift, const float* sums, void* dx, int lddx, void* dres, int lddres,
                        void* dpost, int lddpost, int post_acc, float* dbias_partial,
                        long long M, int C, int act, int dtype, mi355_stream_t s);
+/* The same pass for the LAST of several applications whose incoming gradients all flow to the same post-activation operand (the
+ * recurrent block's x in x + relu(bn(conv(.))), applied t times with shared weights: R2AttU_Net.py:41-44): dpost (+)= dy + ex0 +
+ * ex1 + ex2 + ex3, the earlier applications' incoming gradients (ex1..ex3 may be NULL; row pitch ldex), summed in fp32 and rounded
+ * once — the earlier applications' passes then carry no dpost at all (one pass over d x instead of t read-modify-writes). */
+int mi355_bn_bwd_apply_post4(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,
+                             const float* gamma, const float* mean, const float* invstd, const float* mscale,
+                             const float* mshift, const float* sums, void* dx, int lddx, void* dpost, int lddpost,
+                             int post_acc, const void* ex0, const void* ex1, const void* ex2, const void* ex3, int ldex,
+                             long long M, int C, int act, int dtype, mi355_stream_t s);
 /* The same two passes for a BatchNorm + ReLU layer whose activation also feeds a MaxPool2d(2, 2) (mi355_bn_act_pool2;
  * AttentionUNet.py:61,89-95): dp, the gradient of the POOLED tensor [N][H/2][W/2][C], is added on the fly to the pixels that are
  * the first maximum of their window (torch's tie rule, the activation recomputed from x with mscale / mshift exactly as the

@@ -195,37 +195,45 @@ extern "C" int mi355_bn_eval_coeffs(const float* gamma, const float* beta, const
 }
 
 // ---- apply (+ second normalised operand, + residual, + ReLU) ------------------------------------------
-template <typename T> struct BnActOp {
+// H2 / HR (a second normalised operand, a residual operand) are compile-time: a load under a run-time condition is waited for on the
+// spot, which takes the rest of a fetch batch out of flight (common.hpp, ld16_pol).  The raw convolution output is read streaming
+// (not read again before the backward pass; the default policy measured +0.09 ms per step).
+template <typename T, bool H2 = false, bool HR = false> struct BnActOp {
   static constexpr int EPC = 16 / (int)sizeof(T);
   const T* x; int ldx; const float* scale; const float* shift;
   const T* x2; int ldx2; const float* scale2; const float* shift2;
   const T* res; int ldr;
   T* y; int ldy;
-  int act; int keep;
+  int act;
   float sc[EPC], sh[EPC], sc2[EPC];
   __device__ void load_cols(int c0) {
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
       sc[e] = scale ? scale[c0 + e] : 1.f;
       sh[e] = scale ? shift[c0 + e] : 0.f;
-      sc2[e] = x2 ? scale2[c0 + e] : 0.f;
-      if (x2) sh[e] += shift2[c0 + e];
+      sc2[e] = H2 ? scale2[c0 + e] : 0.f;
+      if constexpr (H2) sh[e] += shift2[c0 + e];
     }
   }
   static constexpr int FETCH_ROWS = 8;
   struct In { Vec16<T> v, v2, vr; };
   __device__ In fetch(size_t row, int c0) const {
     In in;
-    in.v = keep ? ld16<T>(x + row * ldx + c0) : ld16_nt<T>(x + row * ldx + c0);      // (the raw conv output is not read again before the backward pass: nontemporal)
-    if (x2) in.v2 = ld16<T>(x2 + row * ldx2 + c0);
-    if (res) in.vr = ld16<T>(res + row * ldr + c0);
+    in.v = ld16_nt<T>(x + row * ldx + c0);
+    if constexpr (H2) in.v2 = ld16<T>(x2 + row * ldx2 + c0);
+    if constexpr (HR) in.vr = ld16<T>(res + row * ldr + c0);
     return in;
+  }
+  __device__ void pin(In& in) const {
+    pin16(in.v);
+    if constexpr (H2) pin16(in.v2);
+    if constexpr (HR) pin16(in.vr);
   }
   __device__ void finish(const In& in, size_t row, int c0) const {
     float f[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) f[e] = __builtin_fmaf(to_f32<T>(in.v.v[e]), sc[e], sh[e]);      // (fused: the pool-aware backward recomputes it bit for bit)
-    if (x2) {
+    if constexpr (H2) {
 #pragma unroll
       for (int e = 0; e < EPC; ++e) f[e] = __builtin_fmaf(to_f32<T>(in.v2.v[e]), sc2[e], f[e]);      // (mi355_gate_bn_bwd_* recompute it)
     }
@@ -236,9 +244,9 @@ template <typename T> struct BnActOp {
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
       float v = f[e];
-      if (res && !post) v += to_f32<T>(in.vr.v[e]);
+      if (HR && !post) v += to_f32<T>(in.vr.v[e]);
       if (relu) v = fmaxf(v, 0.f);
-      if (res && post) v += to_f32<T>(in.vr.v[e]);
+      if (HR && post) v += to_f32<T>(in.vr.v[e]);
       o.v[e] = from_f32<T>(v);
     }
     st16<T>(y + row * ldy + c0, o);
@@ -252,9 +260,13 @@ extern "C" int mi355_bn_act(const void* x, int ldx, const float* scale, const fl
   MI355_CHECK_ARG(!x2 || (scale2 && shift2), "bn_act: second operand needs scale2/shift2");
   return dispatch_dtype(dtype, "bn_act", [&](auto tag) {
     using T = decltype(tag);
-    const int act_keep = 0;      // (streaming read of the raw convolution output: the default policy measured +0.09 ms per step)
-    BnActOp<T> op{(const T*)x, ldx, scale, shift, (const T*)x2, ldx2, scale2, shift2, (const T*)res, ldr, (T*)y, ldy, act, act_keep};
-    return rowmap_launch<T>(op, M, C, (hipStream_t)s);
+    auto run = [&](auto op) {
+      op.x = (const T*)x; op.ldx = ldx; op.scale = scale; op.shift = shift; op.x2 = (const T*)x2; op.ldx2 = ldx2;
+      op.scale2 = scale2; op.shift2 = shift2; op.res = (const T*)res; op.ldr = ldr; op.y = (T*)y; op.ldy = ldy; op.act = act;
+      return rowmap_launch<T>(op, M, C, (hipStream_t)s);
+    };
+    if (x2) return res ? run(BnActOp<T, true, true>{}) : run(BnActOp<T, true, false>{});
+    return res ? run(BnActOp<T, false, true>{}) : run(BnActOp<T, false, false>{});
   });
 }
 
@@ -262,10 +274,10 @@ extern "C" int mi355_bn_act(const void* x, int ldx, const float* scale, const fl
 // A thread owns one 16-byte channel chunk of one 2 x 2 pixel group: four reads of the raw convolution output, four writes of the
 // activation (the skip connection / gate / next convolution read it), one write of the pooled tensor — the separate pooling pass
 // re-read the whole activation.  Values are pooled AFTER rounding to the storage type, i.e. exactly what mi355_maxpool_fwd reads.
-template <typename T>
+template <typename T, bool HR>
 __global__ __launch_bounds__(256) void bn_act_pool2_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, T* __restrict__ y, int ldy,
-                                                           T* __restrict__ p, int ldp, int N, int H, int W, int C, int act, int keep,
+                                                           T* __restrict__ p, int ldp, int N, int H, int W, int C, int act,
                                                            const T* __restrict__ res = nullptr, int ldr = 0) {
   constexpr int EPC = 16 / (int)sizeof(T);
   const int cp = C / EPC, Ho = H >> 1, Wo = W >> 1;
@@ -283,9 +295,9 @@ __global__ __launch_bounds__(256) void bn_act_pool2_kernel(const T* __restrict__
     Vec16<T> in[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      in[k] = keep ? ld16<T>(x + (r0 + (size_t)(k >> 1) * W + (k & 1)) * ldx + c0) : ld16_nt<T>(x + (r0 + (size_t)(k >> 1) * W + (k & 1)) * ldx + c0);
+      in[k] = ld16_nt<T>(x + (r0 + (size_t)(k >> 1) * W + (k & 1)) * ldx + c0);      // (streaming, as mi355_bn_act)
     Vec16<T> rs[4];
-    if (res) {       // (mi355_bn_act's residual operand: added before the activation, or after it when act bit 1 is set)
+    if constexpr (HR) {       // (mi355_bn_act's residual operand: added before the activation, or after it when act bit 1 is set)
 #pragma unroll
       for (int k = 0; k < 4; ++k) rs[k] = ld16<T>(res + (r0 + (size_t)(k >> 1) * W + (k & 1)) * ldr + c0);
     }
@@ -295,9 +307,9 @@ __global__ __launch_bounds__(256) void bn_act_pool2_kernel(const T* __restrict__
 #pragma unroll
       for (int e = 0; e < EPC; ++e) {
         float v = __builtin_fmaf(to_f32<T>(in[k].v[e]), sc[e], sh[e]);
-        if (res && !(act & 2)) v += to_f32<T>(rs[k].v[e]);
+        if (HR && !(act & 2)) v += to_f32<T>(rs[k].v[e]);
         if (act & 1) v = fmaxf(v, 0.f);
-        if (res && (act & 2)) v += to_f32<T>(rs[k].v[e]);
+        if (HR && (act & 2)) v += to_f32<T>(rs[k].v[e]);
         o.v[e] = from_f32<T>(v);
         const float r = to_f32<T>(o.v[e]);
         m[e] = k == 0 ? r : fmaxf(m[e], r);
@@ -321,11 +333,10 @@ extern "C" int mi355_bn_act_pool2(const void* x, int ldx, const float* scale, co
   MI355_CHECK_ARG(C % epc == 0, "bn_act_pool2: C=%d must be a multiple of %d", C, epc);
   long long blocks = ((long long)N * (H / 2) * (W / 2) * (C / epc) + 255) / 256;
   if (blocks > 256 * 8) blocks = 256 * 8;
-  const int act_keep = 0;      // (see mi355_bn_act)
   return dispatch_dtype(dtype, "bn_act_pool2", [&](auto tag) {
     using T = decltype(tag);
-    hipLaunchKernelGGL((bn_act_pool2_kernel<T>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx, scale, shift, (T*)y, ldy,
-                       (T*)p, ldp, N, H, W, C, act, act_keep);
+    hipLaunchKernelGGL((bn_act_pool2_kernel<T, false>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx, scale, shift, (T*)y, ldy,
+                       (T*)p, ldp, N, H, W, C, act);
     MI355_LAUNCH_CHECK();
     return (int)MI355_OK;
   });
@@ -342,8 +353,12 @@ extern "C" int mi355_bn_act_windows(const void* x, int ldx, const float* scale, 
   if (blocks > 256 * 8) blocks = 256 * 8;
   return dispatch_dtype(dtype, "bn_act_windows", [&](auto tag) {
     using T = decltype(tag);
-    hipLaunchKernelGGL((bn_act_pool2_kernel<T>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx, scale, shift, (T*)y, ldy,
-                       (T*)nullptr, 0, N, H, W, C, act, 0, (const T*)res, ldr);
+    if (res)
+      hipLaunchKernelGGL((bn_act_pool2_kernel<T, true>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx, scale, shift,
+                         (T*)y, ldy, (T*)nullptr, 0, N, H, W, C, act, (const T*)res, ldr);
+    else
+      hipLaunchKernelGGL((bn_act_pool2_kernel<T, false>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx, scale, shift,
+                         (T*)y, ldy, (T*)nullptr, 0, N, H, W, C, act, (const T*)nullptr, 0);
     MI355_LAUNCH_CHECK();
     return (int)MI355_OK;
   });
@@ -384,42 +399,46 @@ static inline int bn_apply_reversed() {
   return rev;
 }
 
-template <typename T> struct BnBwdReduceOp {
+// HASY (the activated tensor is read for the mask) and KEEP (cache policy of the operand reads) are compile-time: see ld16_pol.
+template <typename T, bool HASY = false, bool KEEP = true> struct BnBwdReduceOp {
   static constexpr int NQ = 2;
   static constexpr bool WRITES = false;
   typedef float Acc;
   static constexpr int EPC = 16 / (int)sizeof(T);
   const T* dy; int lddy; const T* y; int ldy; const T* x; int ldx;
-  const float* mean; const float* invstd; const float* mscale; const float* mshift; int act; int keep;
+  const float* mean; const float* invstd; const float* mscale; const float* mshift; int act;
   float mu[EPC], is[EPC], ms[EPC], mt[EPC];
   __device__ void load_cols(int c0) {
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
       mu[e] = mean[c0 + e];
       is[e] = invstd[c0 + e];
-      ms[e] = (act && !y) ? mscale[c0 + e] : 0.f;
-      mt[e] = (act && !y) ? mshift[c0 + e] : 0.f;
+      ms[e] = (act && !HASY) ? mscale[c0 + e] : 0.f;
+      mt[e] = (act && !HASY) ? mshift[c0 + e] : 0.f;
     }
   }
-  #ifndef BN_RED_FETCH
+#ifndef BN_RED_FETCH
 #define BN_RED_FETCH 4
 #endif
   static constexpr int FETCH_ROWS = BN_RED_FETCH;
+#ifdef BN_RED_WGS
+  static constexpr int MAX_WGS = BN_RED_WGS;      // (A/B: workgroups of the read-only pass)
+#endif
   struct In { Vec16<T> g, xv, yv; };
   __device__ In fetch(size_t row, int c0) const {
     In in;
-    // streaming loads (nontemporal): with the three BatchNorm passes reading their operands this way the step is 0.27 ms shorter
-    // (reduce 4.15 -> 4.6 TB/s; the apply pass no longer finds the reduce pass's lines in the memory-side cache and is 1 % slower,
-    // the sum wins) — A/B of all combinations in DESIGN.md section 4
-    if (keep) {        // leave the lines in the memory-side cache for the apply pass that re-reads them next (bn_reduce_keeps)
-      in.g = ld16<T>(dy + row * lddy + c0);
-      in.xv = ld16<T>(x + row * ldx + c0);
-    } else {
-      in.g = ld16_nt<T>(dy + row * lddy + c0);
-      in.xv = ld16_nt<T>(x + row * ldx + c0);
-    }
-    if (act && y) in.yv = ld16<T>(y + row * ldy + c0);
+    // KEEP: the lines stay in the memory-side cache for the apply pass that re-reads them next (bn_reduce_keeps); else streaming
+    // loads (round 2: with the three BatchNorm passes reading their operands that way the step was 0.27 ms shorter; round 3, on a
+    // plan with fewer passes between the two, the default policy won by 0.13 ms) — A/B of all combinations in DESIGN.md section 4
+    in.g = ld16_pol<KEEP, T>(dy + row * lddy + c0);
+    in.xv = ld16_pol<KEEP, T>(x + row * ldx + c0);
+    if constexpr (HASY) in.yv = ld16<T>(y + row * ldy + c0);
     return in;
+  }
+  __device__ void pin(In& in) const {
+    pin16(in.g);
+    pin16(in.xv);
+    if constexpr (HASY) pin16(in.yv);
   }
   __device__ void finish(const In& in, size_t, int, Acc (&acc)[NQ][EPC]) const {
 #pragma unroll
@@ -427,7 +446,7 @@ template <typename T> struct BnBwdReduceOp {
       float gg = to_f32<T>(in.g.v[e]);
       const float xf = to_f32<T>(in.xv.v[e]);
       if (act) {
-        const bool on = y ? (to_f32<T>(in.yv.v[e]) > 0.f) : (xf * ms[e] + mt[e] > 0.f);
+        const bool on = HASY ? (to_f32<T>(in.yv.v[e]) > 0.f) : (xf * ms[e] + mt[e] > 0.f);
         if (!on) gg = 0.f;
       }
       acc[0][e] += gg;
@@ -444,9 +463,14 @@ extern "C" int mi355_bn_bwd_reduce(const void* dy, int lddy, const void* y, int 
   MI355_CHECK_ARG(dy && x && mean && invstd && partial && (!act || y || (mscale && mshift)), "bn_bwd_reduce: null pointer");
   return dispatch_dtype(dtype, "bn_bwd_reduce", [&](auto tag) {
     using T = decltype(tag);
-    const int keep = bn_reduce_keeps(2ll * M * C * (long long)sizeof(T));
-    BnBwdReduceOp<T> op{(const T*)dy, lddy, (const T*)y, ldy, (const T*)x, ldx, mean, invstd, mscale, mshift, act, keep};
-    return rowred_launch<T>(op, M, C, partial, (hipStream_t)s);
+    const bool keep = bn_reduce_keeps(2ll * M * C * (long long)sizeof(T)), hasy = act && y;
+    auto run = [&](auto op) {
+      op.dy = (const T*)dy; op.lddy = lddy; op.y = (const T*)y; op.ldy = ldy; op.x = (const T*)x; op.ldx = ldx;
+      op.mean = mean; op.invstd = invstd; op.mscale = mscale; op.mshift = mshift; op.act = act;
+      return rowred_launch<T>(op, M, C, partial, (hipStream_t)s);
+    };
+    if (hasy) return keep ? run(BnBwdReduceOp<T, true, true>{}) : run(BnBwdReduceOp<T, true, false>{});
+    return keep ? run(BnBwdReduceOp<T, false, true>{}) : run(BnBwdReduceOp<T, false, false>{});
   });
 }
 
@@ -485,16 +509,23 @@ extern "C" int mi355_bn_bwd_finalize(const float* partial, int nblocks, int C, f
   return mi355_bn_bwd_finalize_at(partial, nblocks, 2, 0, 1, C, sums, dgamma, dbeta, acc, s);
 }
 
-template <typename T> struct BnBwdApplyOp {
+// NEX = 4: the post-activation operand's gradient also takes up to four EARLIER incoming gradients (the recurrent block's
+// x + relu(bn(.)) applied t times to the same x, R2AttU_Net.py:41-44): d x = sum over the applications of their incoming gradients,
+// added here in ONE pass by the last of them — one fp32 sum, one rounding — instead of a read-modify-write of d x in every one.
+// HASY / PACC (the activated tensor is read for the mask; dpost accumulates) are compile-time: a load under a run-time condition is
+// branched around AND waited for on the spot (vmcnt(0)), which would take the other rows' loads of the batch out of flight.
+template <typename T, int NEX = 0, bool HASY = false, bool PACC = false, bool KEEP = true> struct BnBwdApplyOp {
   static constexpr int NQ = 1;
   static constexpr bool WRITES = true;
   typedef float Acc;
   static constexpr int EPC = 16 / (int)sizeof(T);
+  static constexpr int NEXA = NEX > 0 ? NEX : 1;
   const T* dy; int lddy; const T* y; int ldy; const T* x; int ldx;
   const float* gamma; const float* mean; const float* invstd; const float* mscale; const float* mshift; const float* sums;
   T* dx; int lddx; T* dres; int lddres; T* dpost; int lddpost; int post_acc;
-  float invM; int C; int act; int keep;
+  float invM; int C; int act;
   long long last;      // >= 0: the pass walks the rows from the END (row r of the sweep is tensor row last - r), see bn_apply_reversed
+  const T* ex[NEXA]; int ldex, nex;      // (NEX > 0) earlier incoming gradients: the first nex are added; all of row pitch ldex
   float mu[EPC], is[EPC], k0[EPC], k1[EPC], gi[EPC], ms[EPC], mt[EPC];
   __device__ void load_cols(int c0) {
 #pragma unroll
@@ -508,29 +539,47 @@ template <typename T> struct BnBwdApplyOp {
       k1[e] = sums[C + c0 + e] * invM;
     }
   }
-  static constexpr int FETCH_ROWS = 4;
-  struct In { Vec16<T> g, xv, yv, pv; };
+  static constexpr int FETCH_ROWS = NEX > 0 ? 2 : 4;
+  struct In { Vec16<T> g, xv, yv, pv, ev[NEXA]; };
   __device__ In fetch(size_t row, int c0) const {
     In in;
     if (last >= 0) row = (size_t)last - row;
-    if (keep) {
-      in.g = ld16<T>(dy + row * lddy + c0);
-      in.xv = ld16<T>(x + row * ldx + c0);
-    } else {
-      in.g = ld16_nt<T>(dy + row * lddy + c0);       // (last reads of both: nontemporal)
-      in.xv = ld16_nt<T>(x + row * ldx + c0);
+    in.g = ld16_pol<KEEP, T>(dy + row * lddy + c0);
+    in.xv = ld16_pol<KEEP, T>(x + row * ldx + c0);
+    if constexpr (HASY) in.yv = ld16<T>(y + row * ldy + c0);
+    if constexpr (PACC) in.pv = ld16<T>(dpost + row * lddpost + c0);
+    if constexpr (NEX > 0) {      // (absent ones point at ex[0]: loaded, not added)
+#pragma unroll
+      for (int j = 0; j < NEX; ++j) in.ev[j] = ld16_nt<T>(ex[j] + row * ldex + c0);      // (their last read)
     }
-    if (act && y) in.yv = ld16<T>(y + row * ldy + c0);
-    if (dpost && post_acc) in.pv = ld16<T>(dpost + row * lddpost + c0);
     return in;
+  }
+  __device__ void pin(In& in) const {
+    pin16(in.g);
+    pin16(in.xv);
+    if constexpr (HASY) pin16(in.yv);
+    if constexpr (PACC) pin16(in.pv);
+    if constexpr (NEX > 0) {
+#pragma unroll
+      for (int j = 0; j < NEX; ++j) pin16(in.ev[j]);
+    }
   }
   __device__ void finish(const In& in, size_t row, int c0, Acc (&acc)[NQ][EPC]) const {
     if (last >= 0) row = (size_t)last - row;
     if (dpost) {      // gradient of an operand added after the activation: the incoming gradient itself
       Vec16<T> pg = in.g;
-      if (post_acc) {
+      if constexpr (PACC || NEX > 0) {
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) pg.v[e] = from_f32<T>(to_f32<T>(in.g.v[e]) + to_f32<T>(in.pv.v[e]));
+        for (int e = 0; e < EPC; ++e) {
+          float v = to_f32<T>(in.g.v[e]);
+          if constexpr (PACC) v += to_f32<T>(in.pv.v[e]);
+          if constexpr (NEX > 0) {
+#pragma unroll
+            for (int j = 0; j < NEX; ++j)
+              if (j < nex) v += to_f32<T>(in.ev[j].v[e]);
+          }
+          pg.v[e] = from_f32<T>(v);
+        }
       }
       st16<T>(dpost + row * lddpost + c0, pg);
     }
@@ -540,7 +589,7 @@ template <typename T> struct BnBwdApplyOp {
       float gg = to_f32<T>(in.g.v[e]);
       const float xf = to_f32<T>(in.xv.v[e]);
       if (act) {
-        const bool on = y ? (to_f32<T>(in.yv.v[e]) > 0.f) : (xf * ms[e] + mt[e] > 0.f);
+        const bool on = HASY ? (to_f32<T>(in.yv.v[e]) > 0.f) : (xf * ms[e] + mt[e] > 0.f);
         if (!on) gg = 0.f;
       }
       const float xh = (xf - mu[e]) * is[e];
@@ -554,21 +603,72 @@ template <typename T> struct BnBwdApplyOp {
   }
 };
 
+template <typename T, int NEX, bool HASY, bool PACC, bool KEEP>
+static int bn_bwd_apply_launch(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,
+                               const float* gamma, const float* mean, const float* invstd, const float* mscale,
+                               const float* mshift, const float* sums, void* dx, int lddx, void* dres, int lddres,
+                               void* dpost, int lddpost, const void* const* ex, int ldex,
+                               float* dbias_partial, long long M, int C, int act, mi355_stream_t s) {
+  const float invM = (float)(1.0 / (double)M);
+  const long long last = bn_apply_reversed() ? M - 1 : -1ll;
+  BnBwdApplyOp<T, NEX, HASY, PACC, KEEP> op{(const T*)dy, lddy, (const T*)y, ldy, (const T*)x, ldx, gamma, mean, invstd,
+                                            mscale, mshift, sums, (T*)dx, lddx, (T*)dres, lddres, (T*)dpost, lddpost, PACC ? 1 : 0, invM, C,
+                                            act, last, {nullptr}, ldex, 0};
+  if constexpr (NEX > 0) {
+    for (int j = 0; j < NEX; ++j) {
+      op.ex[j] = (const T*)(ex[j] ? ex[j] : ex[0]);
+      if (ex[j]) op.nex = j + 1;
+    }
+  }
+  return rowred_launch<T>(op, M, C, dbias_partial, (hipStream_t)s);
+}
+
+static int bn_bwd_apply_impl(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,
+                             const float* gamma, const float* mean, const float* invstd, const float* mscale,
+                             const float* mshift, const float* sums, void* dx, int lddx, void* dres, int lddres,
+                             void* dpost, int lddpost, int post_acc, const void* const* ex, int ldex,
+                             float* dbias_partial, long long M, int C, int act, int dtype, mi355_stream_t s) {
+  MI355_CHECK_ARG(dy && x && gamma && mean && invstd && sums && dx && (!act || y || (mscale && mshift)), "bn_bwd_apply: null pointer");
+  if (ex) {
+    for (int j = 1; j < 4; ++j) MI355_CHECK_ARG(!ex[j] || ex[j - 1], "bn_bwd_apply_post4: the earlier gradients must be given without gaps");
+  }
+  return dispatch_dtype(dtype, "bn_bwd_apply", [&](auto tag) {
+    using T = decltype(tag);
+    const bool hasy = act && y, pacc = dpost && post_acc;
+    const bool keep = bn_apply_keeps(2ll * M * C * (long long)sizeof(T));
+#define MI355_APPLY(NEX, HASY, PACC)                                                                                                       \
+  (keep ? bn_bwd_apply_launch<T, NEX, HASY, PACC, true>(dy, lddy, y, ldy, x, ldx, gamma, mean, invstd, mscale, mshift, sums, dx, lddx,     \
+                                                        dres, lddres, dpost, lddpost, ex, ldex, dbias_partial, M, C, act, s)               \
+        : bn_bwd_apply_launch<T, NEX, HASY, PACC, false>(dy, lddy, y, ldy, x, ldx, gamma, mean, invstd, mscale, mshift, sums, dx, lddx,    \
+                                                         dres, lddres, dpost, lddpost, ex, ldex, dbias_partial, M, C, act, s))
+    if (ex) {
+      if (hasy) return pacc ? MI355_APPLY(4, true, true) : MI355_APPLY(4, true, false);
+      return pacc ? MI355_APPLY(4, false, true) : MI355_APPLY(4, false, false);
+    }
+    if (hasy) return pacc ? MI355_APPLY(0, true, true) : MI355_APPLY(0, true, false);
+    return pacc ? MI355_APPLY(0, false, true) : MI355_APPLY(0, false, false);
+#undef MI355_APPLY
+  });
+}
+
 extern "C" int mi355_bn_bwd_apply(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,
                                   const float* gamma, const float* mean, const float* invstd, const float* mscale,
                                   const float* mshift, const float* sums, void* dx, int lddx, void* dres, int lddres,
                                   void* dpost, int lddpost, int post_acc,
                                   float* dbias_partial, long long M, int C, int act, int dtype, mi355_stream_t s) {
-  MI355_CHECK_ARG(dy && x && gamma && mean && invstd && sums && dx && (!act || y || (mscale && mshift)), "bn_bwd_apply: null pointer");
-  const float invM = (float)(1.0 / (double)M);
-  const int apply_keep = bn_apply_keeps(2ll * M * C * (dtype_is_2byte(dtype) ? 2 : 4));
-  return dispatch_dtype(dtype, "bn_bwd_apply", [&](auto tag) {
-    using T = decltype(tag);
-    BnBwdApplyOp<T> op{(const T*)dy, lddy, (const T*)y, ldy, (const T*)x, ldx, gamma, mean, invstd,
-                       mscale, mshift, sums, (T*)dx, lddx, (T*)dres, lddres, (T*)dpost, lddpost, post_acc, invM, C, act, apply_keep,
-                       bn_apply_reversed() ? M - 1 : -1ll};
-    return rowred_launch<T>(op, M, C, dbias_partial, (hipStream_t)s);
-  });
+  return bn_bwd_apply_impl(dy, lddy, y, ldy, x, ldx, gamma, mean, invstd, mscale, mshift, sums, dx, lddx, dres, lddres, dpost, lddpost,
+                           post_acc, nullptr, 0, dbias_partial, M, C, act, dtype, s);
+}
+
+extern "C" int mi355_bn_bwd_apply_post4(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,
+                                        const float* gamma, const float* mean, const float* invstd, const float* mscale,
+                                        const float* mshift, const float* sums, void* dx, int lddx, void* dpost, int lddpost,
+                                        int post_acc, const void* ex0, const void* ex1, const void* ex2, const void* ex3, int ldex,
+                                        long long M, int C, int act, int dtype, mi355_stream_t s) {
+  MI355_CHECK_ARG(dpost && ex0, "bn_bwd_apply_post4: the post-activation operand's gradient and at least one earlier gradient expected");
+  const void* ex[4] = {ex0, ex1, ex2, ex3};
+  return bn_bwd_apply_impl(dy, lddy, y, ldy, x, ldx, gamma, mean, invstd, mscale, mshift, sums, dx, lddx, nullptr, 0, dpost, lddpost,
+                           post_acc, ex, ldex, nullptr, M, C, act, dtype, s);
 }
 
 // ---- plain column sums (bias gradients) -------------------------------------------------------------
@@ -579,13 +679,12 @@ extern "C" int mi355_bn_bwd_apply(const void* dy, int lddy, const void* y, int l
 // batch (the mapping of bn_act_pool2_kernel: a wave instruction covers 64 / tpr pixels two apart, the four together every byte of
 // two image-row segments), a workgroup pass rp windows = two image rows x 2 * rp pixels.  Geometry the host checks: tpr = C / EPC
 // a power of two, W a power-of-two multiple of 2 * rp.
-template <typename T, bool HASDY> struct BnBwdPool2 {
+template <typename T, bool HASDY, bool KEEP> struct BnBwdPool2 {
   static constexpr int EPC = 16 / (int)sizeof(T);
   const T* dy; int lddy; const T* dp; int lddp; const T* x; int ldx;
   const float* mean; const float* invstd; const float* mscale; const float* mshift;
   int W, lrp, lwb;               // rp = 1 << lrp windows of a workgroup pass, W = (2 * rp) << lwb
-  int keep;                      // reduce pass: default cache policy (the apply pass re-reads the operands next); apply: streaming
-  float mu[EPC], is[EPC], ms[EPC], mt[EPC];
+  float mu[EPC], is[EPC], ms[EPC], mt[EPC];      // (KEEP: cache policy of the operand reads, compile-time: see ld16_pol)
   __device__ void load_common(int c0) {
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { mu[e] = mean[c0 + e]; is[e] = invstd[c0 + e]; ms[e] = mscale[c0 + e]; mt[e] = mshift[c0 + e]; }
@@ -599,10 +698,18 @@ template <typename T, bool HASDY> struct BnBwdPool2 {
     for (int b = 0; b < 4; ++b) p.pix[b] = (size_t)(2 * R + (b >> 1)) * W + 2 * wcol + (b & 1);
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      if constexpr (HASDY) p.gv[b] = keep ? ld16<T>(dy + p.pix[b] * lddy + c0) : ld16_nt<T>(dy + p.pix[b] * lddy + c0);
-      p.xv[b] = keep ? ld16<T>(x + p.pix[b] * ldx + c0) : ld16_nt<T>(x + p.pix[b] * ldx + c0);
+      if constexpr (HASDY) p.gv[b] = ld16_pol<KEEP, T>(dy + p.pix[b] * lddy + c0);
+      p.xv[b] = ld16_pol<KEEP, T>(x + p.pix[b] * ldx + c0);
     }
-    p.pv = keep ? ld16<T>(dp + ((size_t)R * (W >> 1) + wcol) * lddp + c0) : ld16_nt<T>(dp + ((size_t)R * (W >> 1) + wcol) * lddp + c0);
+    p.pv = ld16_pol<KEEP, T>(dp + ((size_t)R * (W >> 1) + wcol) * lddp + c0);
+  }
+  __device__ void pin(Px& p) const {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if constexpr (HASDY) pin16(p.gv[b]);
+      pin16(p.xv[b]);
+    }
+    pin16(p.pv);
   }
   // g[b]: the gradient reaching the activation of row b, ReLU-masked
   __device__ void grads(const Px& p, int e, float (&g)[4]) const {
@@ -623,14 +730,14 @@ template <typename T, bool HASDY> struct BnBwdPool2 {
   }
 };
 
-template <typename T, bool HASDY> struct BnBwdReducePool2Op : BnBwdPool2<T, HASDY> {
+template <typename T, bool HASDY, bool KEEP = true> struct BnBwdReducePool2Op : BnBwdPool2<T, HASDY, KEEP> {
   static constexpr int NQ = 2;
   static constexpr bool WRITES = false;
   static constexpr int BATCH_ROWS = 4;
   typedef float Acc;
   static constexpr int EPC = 16 / (int)sizeof(T);
   __device__ void load_cols(int c0) { this->load_common(c0); }
-  __device__ void finish(const typename BnBwdPool2<T, HASDY>::Px& p, int, int, Acc (&acc)[NQ][EPC]) const {
+  __device__ void finish(const typename BnBwdPool2<T, HASDY, KEEP>::Px& p, int, int, Acc (&acc)[NQ][EPC]) const {
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
       float g[4];
@@ -644,7 +751,7 @@ template <typename T, bool HASDY> struct BnBwdReducePool2Op : BnBwdPool2<T, HASD
   }
 };
 
-template <typename T, bool HASDY> struct BnBwdApplyPool2Op : BnBwdPool2<T, HASDY> {
+template <typename T, bool HASDY, bool KEEP = true> struct BnBwdApplyPool2Op : BnBwdPool2<T, HASDY, KEEP> {
   static constexpr int NQ = 1;
   static constexpr bool WRITES = true;
   static constexpr int BATCH_ROWS = 4;
@@ -661,7 +768,7 @@ template <typename T, bool HASDY> struct BnBwdApplyPool2Op : BnBwdPool2<T, HASDY
       k1[e] = sums[C + c0 + e] * invM;
     }
   }
-  __device__ void finish(const typename BnBwdPool2<T, HASDY>::Px& p, int, int c0, Acc (&acc)[NQ][EPC]) const {
+  __device__ void finish(const typename BnBwdPool2<T, HASDY, KEEP>::Px& p, int, int c0, Acc (&acc)[NQ][EPC]) const {
     Vec16<T> o[4];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
@@ -706,7 +813,6 @@ template <typename T, typename Op> static void fill_pool2(Op& op, const void* dy
   op.dy = (const T*)dy; op.lddy = lddy; op.dp = (const T*)dp; op.lddp = lddp; op.x = (const T*)x; op.ldx = ldx;
   op.mean = mean; op.invstd = invstd; op.mscale = mscale; op.mshift = mshift;
   op.W = W; op.lrp = exact_log2(rp); op.lwb = exact_log2(W / (2 * rp));
-  op.keep = 0;
 }
 
 extern "C" int mi355_bn_bwd_reduce_pool2(const void* dy, int lddy, const void* dp, int lddp, const void* x, int ldx, const float* mean,
@@ -718,10 +824,11 @@ extern "C" int mi355_bn_bwd_reduce_pool2(const void* dy, int lddy, const void* d
     using T = decltype(tag);
     auto run = [&](auto op) {
       fill_pool2<T>(op, dy, lddy, dp, lddp, x, ldx, mean, invstd, mscale, mshift, W, C);
-      op.keep = bn_reduce_keeps(2ll * N * H * W * C * (long long)sizeof(T));
       return rowred_launch<T>(op, (long long)N * H * W, C, partial, (hipStream_t)s);
     };
-    return dy ? run(BnBwdReducePool2Op<T, true>{}) : run(BnBwdReducePool2Op<T, false>{});
+    const bool keep = bn_reduce_keeps(2ll * N * H * W * C * (long long)sizeof(T));
+    if (dy) return keep ? run(BnBwdReducePool2Op<T, true, true>{}) : run(BnBwdReducePool2Op<T, true, false>{});
+    return keep ? run(BnBwdReducePool2Op<T, false, true>{}) : run(BnBwdReducePool2Op<T, false, false>{});
   });
 }
 
@@ -735,11 +842,12 @@ extern "C" int mi355_bn_bwd_apply_pool2(const void* dy, int lddy, const void* dp
     using T = decltype(tag);
     auto run = [&](auto op) {
       fill_pool2<T>(op, dy, lddy, dp, lddp, x, ldx, mean, invstd, mscale, mshift, W, C);
-      op.keep = bn_apply_keeps(2ll * M * C * (long long)sizeof(T));
       op.gamma = gamma; op.sums = sums; op.dx = (T*)dx; op.lddx = lddx; op.invM = (float)(1.0 / (double)M); op.C = C;
       return rowred_launch<T>(op, M, C, nullptr, (hipStream_t)s);
     };
-    return dy ? run(BnBwdApplyPool2Op<T, true>{}) : run(BnBwdApplyPool2Op<T, false>{});
+    const bool keep = bn_apply_keeps(2ll * M * C * (long long)sizeof(T));
+    if (dy) return keep ? run(BnBwdApplyPool2Op<T, true, true>{}) : run(BnBwdApplyPool2Op<T, true, false>{});
+    return keep ? run(BnBwdApplyPool2Op<T, false, true>{}) : run(BnBwdApplyPool2Op<T, false, false>{});
   });
 }
 

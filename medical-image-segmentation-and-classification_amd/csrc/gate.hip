@@ -274,12 +274,11 @@ extern "C" int mi355_gate_psi_fwd(const void* g1, int ldg, const void* x1, int l
 // serve both branches at once: reduce reads g1, x1 and dz and leaves five quantities per channel,
 //   q0 = sum dp, q1 = sum dp * xhat_g, q2 = sum dp * xhat_x, q3 = sum dz * p (the psi weight's gradient), q4 = sum dz (its bias's);
 // apply reads the same and writes both branches' input gradients.
-template <typename T, bool TWO> struct GateBnBwd {
+template <typename T, bool TWO, bool KEEP> struct GateBnBwd {
   static constexpr int EPC = 16 / (int)sizeof(T);
   const float* dz; const T* g1; int ldg; const T* x1; int ldx;
   const float* scale_g; const float* shift_g; const float* scale_x; const float* shift_x;
   const float* mean_g; const float* invstd_g; const float* mean_x; const float* invstd_x; const float* w;
-  int keep;                      // reduce pass: default cache policy for g1 / x1 (the apply pass re-reads them next); apply: streaming
   float sg[EPC], sx[EPC], sh[EPC], mg[EPC], ig[EPC], mx[EPC], ix[EPC], wr[EPC];
   __device__ void load_common(int c0) {
 #pragma unroll
@@ -298,15 +297,15 @@ template <typename T, bool TWO> struct GateBnBwd {
   struct In { Vec16<T> gv, xv; float d; };
   __device__ In fetch(size_t row, int c0) const {
     In in;
-    if (keep) {
-      in.gv = ld16_plain<T>(g1 + row * ldg + c0);
-      if constexpr (TWO) in.xv = ld16_plain<T>(x1 + row * ldx + c0);
-    } else {
-      in.gv = ld16_nt<T>(g1 + row * ldg + c0);
-      if constexpr (TWO) in.xv = ld16_nt<T>(x1 + row * ldx + c0);
-    }
+    in.gv = ld16_pol<KEEP, T>(g1 + row * ldg + c0);      // (KEEP: cache policy of the branch reads, compile-time: see ld16_pol)
+    if constexpr (TWO) in.xv = ld16_pol<KEEP, T>(x1 + row * ldx + c0);
     in.d = dz[row];
     return in;
+  }
+  __device__ void pin(In& in) const {
+    pin16(in.gv);
+    if constexpr (TWO) pin16(in.xv);
+    asm volatile("" : "+v"(in.d) : : "memory");
   }
   // the activation as the forward stored it (BnActOp::finish with a second operand and ReLU)
   __device__ float act(const In& in, int e) const {
@@ -319,13 +318,13 @@ template <typename T, bool TWO> struct GateBnBwd {
   __device__ float dpsi(const In& in, int e, float p) const { return p > 0.f ? to_f32<T>(from_f32<T>(in.d * wr[e])) : 0.f; }
 };
 
-template <typename T, bool TWO> struct GateBnBwdReduceOp : GateBnBwd<T, TWO> {
+template <typename T, bool TWO, bool KEEP = true> struct GateBnBwdReduceOp : GateBnBwd<T, TWO, KEEP> {
   static constexpr int MAX_WGS = 512;         // ≈20 VALU instructions per element: two waves per SIMD (scripts/gate_bench.py: 256 / 512 / 768 = 3.9 / 4.8 / 4.6 TB/s)
   static constexpr int NQ = 5;
   static constexpr bool WRITES = false;
   typedef float Acc;
   static constexpr int EPC = 16 / (int)sizeof(T);
-  using typename GateBnBwd<T, TWO>::In;
+  using typename GateBnBwd<T, TWO, KEEP>::In;
   __device__ void load_cols(int c0) { this->load_common(c0); }
   __device__ void finish(const In& in, size_t, int, Acc (&acc)[NQ][EPC]) const {
 #pragma unroll
@@ -341,13 +340,13 @@ template <typename T, bool TWO> struct GateBnBwdReduceOp : GateBnBwd<T, TWO> {
   }
 };
 
-template <typename T, bool TWO> struct GateBnBwdApplyOp : GateBnBwd<T, TWO> {
+template <typename T, bool TWO, bool KEEP = true> struct GateBnBwdApplyOp : GateBnBwd<T, TWO, KEEP> {
   static constexpr int MAX_WGS = 512;         // (256 / 512 / 768 workgroups = 5.3 / 5.9 / 5.9 TB/s)
   static constexpr int NQ = 1;
   static constexpr bool WRITES = true;
   typedef float Acc;
   static constexpr int EPC = 16 / (int)sizeof(T);
-  using typename GateBnBwd<T, TWO>::In;
+  using typename GateBnBwd<T, TWO, KEEP>::In;
   const float* gamma_g; const float* gamma_x; const float* sums_g; const float* sums_x;
   T* dg; int lddg; T* dx; int lddx; float invM; int C;
   float kg0[EPC], kg1[EPC], gg[EPC], kx0[EPC], kx1[EPC], gx[EPC];
@@ -384,7 +383,6 @@ template <typename T, typename Op> static void fill_gate_bn(Op& op, const float*
   op.scale_g = co[0]; op.shift_g = co[1]; op.mean_g = co[2]; op.invstd_g = co[3];
   op.scale_x = co[4]; op.shift_x = co[5]; op.mean_x = co[6]; op.invstd_x = co[7];
   op.w = w;
-  op.keep = 0;
 }
 
 extern "C" int mi355_gate_bn_bwd_reduce(const float* dz, const void* g1, int ldg, const void* x1, int ldx, const float* scale_g,
@@ -397,16 +395,13 @@ extern "C" int mi355_gate_bn_bwd_reduce(const float* dz, const void* g1, int ldg
   return dispatch_dtype(dtype, "gate_bn_bwd_reduce", [&](auto tag) {
     using T = decltype(tag);
     static const int nt = getenv("MI355_BN_REDUCE_NT") ? atoi(getenv("MI355_BN_REDUCE_NT")) : 0;      // (see bn.hip: bn_reduce_keeps)
-    if (x1) {
-      GateBnBwdReduceOp<T, true> op;
-      fill_gate_bn<T>(op, dz, g1, ldg, x1, ldx, co, w);
-      op.keep = !nt;
+    auto run = [&](auto op) {
+      fill_gate_bn<T>(op, dz, g1, ldg, x1, x1 ? ldx : 0, co, w);
       return rowred_launch<T>(op, M, C, partial, (hipStream_t)s);
-    }
-    GateBnBwdReduceOp<T, false> op;        // one normalised operand (quantity 2 of the partial rows stays zero)
-    fill_gate_bn<T>(op, dz, g1, ldg, nullptr, 0, co, w);
-    op.keep = !nt;
-    return rowred_launch<T>(op, M, C, partial, (hipStream_t)s);
+    };
+    if (x1) return nt ? run(GateBnBwdReduceOp<T, true, false>{}) : run(GateBnBwdReduceOp<T, true, true>{});
+    // one normalised operand (quantity 2 of the partial rows stays zero)
+    return nt ? run(GateBnBwdReduceOp<T, false, false>{}) : run(GateBnBwdReduceOp<T, false, true>{});
   });
 }
 
@@ -423,12 +418,12 @@ extern "C" int mi355_gate_bn_bwd_apply(const float* dz, const void* g1, int ldg,
     static const int apply_nt = getenv("MI355_BN_APPLY_NT") ? atoi(getenv("MI355_BN_APPLY_NT")) : 0;      // (see bn.hip: bn_apply_keeps)
     auto run = [&](auto op) {
       fill_gate_bn<T>(op, dz, g1, ldg, x1, ldx, co, w);
-      op.keep = !apply_nt;
       op.gamma_g = gamma_g; op.gamma_x = gamma_x; op.sums_g = sums_g; op.sums_x = sums_x;
       op.dg = (T*)dg1; op.lddg = lddg; op.dx = (T*)dx1; op.lddx = lddx; op.invM = (float)(1.0 / (double)M); op.C = C;
       return rowred_launch<T>(op, M, C, nullptr, (hipStream_t)s);
     };
-    return x1 ? run(GateBnBwdApplyOp<T, true>{}) : run(GateBnBwdApplyOp<T, false>{});
+    if (x1) return apply_nt ? run(GateBnBwdApplyOp<T, true, false>{}) : run(GateBnBwdApplyOp<T, true, true>{});
+    return apply_nt ? run(GateBnBwdApplyOp<T, false, false>{}) : run(GateBnBwdApplyOp<T, false, true>{});
   });
 }
 

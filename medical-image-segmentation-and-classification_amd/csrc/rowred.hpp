@@ -52,6 +52,21 @@ template <typename Op> struct has_fetch<Op, std::void_t<typename Op::In>> : std:
 // rows (r = its first one) to pixels ITSELF (2 x 2-window aware orders); M is a multiple of the batch and every thread is
 // active (the host checks both).
 template <typename Op, typename = void> struct has_batch : std::false_type {};
+// An op with `pin(In&)` (or `pin(Px&)`) passes every register its fetch loaded through pin16 below (an empty volatile asm with a
+// memory clobber): the kernels call it for row b right in front of finish(row b), behind the fetch loop, which makes "every load
+// of the batch is ISSUED before any row is finished" a dependence the compiler has to keep (loads do not move across the first
+// pin, a row's arithmetic does not move in front of its own), while rows b + 1 .. stay in flight during row b's arithmetic.
+// Left alone, hipcc hoists the first rows' arithmetic in between the loads and sinks the last row's loads behind the first waits —
+// bn_bwd_reduce issued its eighth load behind an s_waitcnt vmcnt(0): one dependent round trip per batch, 3.3 TB/s.
+template <typename Op, typename X, typename = void> struct has_pin : std::false_type {};
+template <typename Op, typename X> struct has_pin<Op, X, std::void_t<decltype(std::declval<const Op&>().pin(std::declval<X&>()))>> : std::true_type {};
+template <typename V> __device__ __forceinline__ void pin16(V& v) {
+  static_assert(sizeof(V) == 16, "a 16-byte load result");
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  u32x4_t w = __builtin_bit_cast(u32x4_t, v);
+  asm volatile("" : "+v"(w) : : "memory");
+  v = __builtin_bit_cast(V, w);
+}
 template <typename Op> struct has_batch<Op, std::void_t<decltype(Op::BATCH_ROWS)>> : std::true_type {};
 
 // Op contract:
@@ -89,6 +104,7 @@ __global__ __launch_bounds__(256) void rowred_kernel(Op op, RowRedGeom g, float*
       for (long long r = (long long)blockIdx.x * g.rp * B; r < g.M; r += st) {
         typename Op::Px p;
         op.fetch(r, ty, c0, p);
+        if constexpr (has_pin<Op, typename Op::Px>::value) op.pin(p);      // (all loads of the batch issued before the arithmetic: see has_pin)
         op.finish(p, ty, c0, acc);
       }
     } else if constexpr (has_fetch<Op>::value) {
@@ -103,8 +119,14 @@ __global__ __launch_bounds__(256) void rowred_kernel(Op op, RowRedGeom g, float*
           typename Op::In in[B];
 #pragma unroll
           for (int b = 0; b < B; ++b) in[b] = op.fetch((size_t)(r + (long long)b * g.rp), c0);
+          // every load of the batch is ISSUED before the first row is finished: left alone, the scheduler sinks the later rows'
+          // loads towards their uses (a read-only reduction has no store to hold them back) and two or three rows are in flight
+          // instead of B: Op::pin, see has_pin above
 #pragma unroll
-          for (int b = 0; b < B; ++b) op.finish(in[b], (size_t)(r + (long long)b * g.rp), c0, acc);
+          for (int b = 0; b < B; ++b) {
+            if constexpr (has_pin<Op, typename Op::In>::value) op.pin(in[b]);      // (waits for row b only; rows b + 1 .. stay in flight)
+            op.finish(in[b], (size_t)(r + (long long)b * g.rp), c0, acc);
+          }
         } else {
           for (long long q = r; q < g.M; q += g.rp) op.finish(op.fetch((size_t)q, c0), (size_t)q, c0, acc);
         }
@@ -215,7 +237,10 @@ __global__ __launch_bounds__(256) void rowmap_kernel(Op op, long long M, int cp)
 #pragma unroll
           for (int b = 0; b < B; ++b) in[b] = op.fetch((size_t)(r + b * rp), c * EPC);
 #pragma unroll
-          for (int b = 0; b < B; ++b) op.finish(in[b], (size_t)(r + b * rp), c * EPC);
+          for (int b = 0; b < B; ++b) {
+            if constexpr (has_pin<Op, typename Op::In>::value) op.pin(in[b]);      // (all loads of the batch issued before the first finish: see has_pin)
+            op.finish(in[b], (size_t)(r + b * rp), c * EPC);
+          }
         } else {
           for (long long q = r; q < M; q += rp) op.finish(op.fetch((size_t)q, c * EPC), (size_t)q, c * EPC);
         }

@@ -36,11 +36,13 @@ BN_ACT_WINDOWS = os.environ.get("MI355_BN_ACT_WINDOWS", "1") != "0"  # plain Bat
 STATIC_PACKS = os.environ.get("MI355_STATIC_PACKS", "1") != "0"     # weight packs of FROZEN parameters are refreshed when the parameters change, not every step
 BN_ACT_WINDOWS_RES = os.environ.get("MI355_BN_ACT_WINDOWS_RES", "1") != "0"   # ... and the passes with a residual operand
 FUSE_RESIDUAL = os.environ.get("MI355_FUSE_RESIDUAL", "1") != "0"   # RRCNN_block's x0 + RCNN(x0) inside the last BatchNorm apply pass (A/B switch)
+DEFER_POST = os.environ.get("MI355_DEFER_POST", "1") != "0"         # recurrent block: d x = the SUM of its applications' incoming gradients, formed in one pass by the last of them (A/B switch)
 
 
 class T:
     """NHWC activation handle: rows of C channels with channel stride ld inside `buf`."""
-    __slots__ = ("buf", "off", "N", "H", "W", "C", "ld", "_ng", "_grad", "parent", "_written", "name", "_plain_bn_relu", "_lazy_pool", "_bn_src", "_lazy_head")
+    __slots__ = ("buf", "off", "N", "H", "W", "C", "ld", "_ng", "_grad", "parent", "_written", "name", "_plain_bn_relu", "_lazy_pool", "_bn_src", "_lazy_head",
+                 "_post_uses", "_post_seen", "_post_pending")
 
     def __init__(self, buf, off, N, H, W, C, ld, parent=None):
         self.buf, self.off = buf, off
@@ -54,6 +56,9 @@ class T:
         self._lazy_pool = None          # gradient of a MaxPool2d(2, 2) of this tensor left to the producer's BatchNorm backward
         self._bn_src = None             # (raw convolution output, BatchNorm coefficient buffers) this activation was computed from
         self._lazy_head = None          # (dz, conv): the one-channel convolution whose backward the producer's BatchNorm passes compute
+        self._post_uses = 0             # conv_bn_act(..., post_add=this) applications in the forward plan / met so far in backward order
+        self._post_seen = 0
+        self._post_pending = []         # their incoming gradients not yet added into this tensor's gradient (Builder._bn_bwd)
 
     @property
     def needs_grad(self):
@@ -806,8 +811,26 @@ class Builder:
         # apply pass reads it anyway and writes / accumulates it (no separate mi355_add pass over da)
         pg, pacc = None, 0
         if post_to is not None and post_to.needs_grad:
-            pacc = self.acc_flag(post_to)
-            pg = self.grad_of(post_to)
+            # Several applications add the SAME operand (the recurrent block's x, R2AttU_Net.py:41-44): their incoming gradients are
+            # left pending and the last application's pass adds them all into d x at once (mi355_bn_bwd_apply_post4: up to four
+            # earlier ones; one fp32 sum and one rounding instead of a read-modify-write of d x per application)
+            post_to._post_seen += 1
+            pend = post_to._post_pending
+            last_one = post_to._post_seen >= post_to._post_uses
+            if DEFER_POST and dres is None and not last_one and len(pend) < 4 and all(t.ld == da.ld for t in pend):
+                pend.append(da)
+            else:
+                pacc = self.acc_flag(post_to)
+                pg = self.grad_of(post_to)
+                if pend:
+                    ex = pend + [None] * (4 - len(pend))
+                    self.bwd.append(Launch("mi355_bn_bwd_apply_post4", da, da.ld, am, am.ld if am is not None else 0, y, y.ld, bn.weight,
+                                           st["mean"], st["invstd"], st["scale"], st["shift"], sums, dy, dy.ld, pg, pg.ld,
+                                           1 if pacc else 0, *ex, pend[0].ld, y.M, C, 1 if act else 0, self.code,
+                                           nbytes=(4 + (am is not None) + (1 if pacc else 0) + len(pend)) * y.M * C * self.esz))
+                    post_to._post_pending = []
+                    assert dres is None
+                    return dy
         self.bwd.append(Launch("mi355_bn_bwd_apply", da, da.ld, am, am.ld if am is not None else 0, y, y.ld, bn.weight,
                                st["mean"], st["invstd"], st["scale"], st["shift"], sums, dy, dy.ld,
                                dres, dres.ld if dres is not None else 0, pg, pg.ld if pg is not None else 0, 1 if pacc else 0,
@@ -844,6 +867,8 @@ class Builder:
             a, _ = self.conv_raw(x, conv, up, out=out, relu=act, fold=(sc, fb))
             a.needs_grad = False
             return a
+        if post_add is not None:
+            post_add._post_uses += 1
         y, conv_bwd = self.conv_raw(x, conv, up, stats=True)
         st = self._bn_coeffs(y, bn, self._last_stat_rows)
         a = out if out is not None else self.new_tensor(y.N, y.H, y.W, y.C)

@@ -215,7 +215,10 @@ template <typename T, bool H2 = false, bool HR = false> struct BnActOp {
       if constexpr (H2) sh[e] += shift2[c0 + e];
     }
   }
-  static constexpr int FETCH_ROWS = 8;
+#ifndef BN_ACT_FETCH
+#define BN_ACT_FETCH 8
+#endif
+  static constexpr int FETCH_ROWS = BN_ACT_FETCH;
   struct In { Vec16<T> v, v2, vr; };
   __device__ In fetch(size_t row, int c0) const {
     In in;
@@ -539,7 +542,10 @@ template <typename T, int NEX = 0, bool HASY = false, bool PACC = false, bool KE
       k1[e] = sums[C + c0 + e] * invM;
     }
   }
-  static constexpr int FETCH_ROWS = NEX > 0 ? 2 : 4;
+#ifndef BN_APPLY_FETCH
+#define BN_APPLY_FETCH 4
+#endif
+  static constexpr int FETCH_ROWS = NEX > 0 ? 2 : BN_APPLY_FETCH;
   struct In { Vec16<T> g, xv, yv, pv, ev[NEXA]; };
   __device__ In fetch(size_t row, int c0) const {
     In in;

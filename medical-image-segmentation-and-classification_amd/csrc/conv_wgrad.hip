@@ -422,27 +422,57 @@ extern "C" int mi355_conv2d_wgrad_multi(const void* x0, const void* dy0, const v
 // the 32 split lanes are folded through LDS, and the result is written transposed so that the
 // parameter-gradient stores are contiguous runs of 32*taps floats.
 #define WR_CI 32
+// TAPS > 0: the tap count at compile time — a thread's partial sums of ALL taps ride in registers and the loads of a split pair
+// (2 x TAPS of them) are in flight together; with the run-time count the loop fetched two floats per trip and waited for them.
+template <int TAPS>
 __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, float* __restrict__ dw, int Co,
-                                                            int Ci, int Ci_real, int taps, int transposed, float beta, int KL) {
+                                                            int Ci, int Ci_real, int taps_rt, int transposed, float beta, int KL) {
   extern __shared__ float tile[];                 // [KL][taps][WR_CI + 1]
+  const int taps = TAPS > 0 ? TAPS : taps_rt;
   const int ciTiles = (Ci + WR_CI - 1) / WR_CI;
   const int co = blockIdx.x / ciTiles, ci0 = (blockIdx.x % ciTiles) * WR_CI;
   const size_t total = (size_t)Co * taps * Ci;
   const int cl = threadIdx.x % WR_CI, kl = threadIdx.x / WR_CI;
   const int ci = ci0 + cl;
   const int tstride = taps * (WR_CI + 1);
-  for (int tap = 0; tap < taps; ++tap) {
-    float s0 = 0.f, s1 = 0.f;
+  if constexpr (TAPS > 0) {
+    float s0[TAPS], s1[TAPS];
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) { s0[tap] = 0.f; s1[tap] = 0.f; }
     if (ci < Ci) {
-      const float* p = ws + ((size_t)co * taps + tap) * Ci + ci;
+      const float* p = ws + (size_t)co * TAPS * Ci + ci;
       int k = kl;
       for (; k + KL < splits; k += 2 * KL) {
-        s0 += p[(size_t)k * total];
-        s1 += p[(size_t)(k + KL) * total];
+        float a[TAPS], b[TAPS];
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+          a[tap] = p[(size_t)k * total + (size_t)tap * Ci];
+          b[tap] = p[(size_t)(k + KL) * total + (size_t)tap * Ci];
+        }
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) { s0[tap] += a[tap]; s1[tap] += b[tap]; }
       }
-      if (k < splits) s0 += p[(size_t)k * total];
+      if (k < splits) {
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) s0[tap] += p[(size_t)k * total + (size_t)tap * Ci];
+      }
     }
-    tile[kl * tstride + tap * (WR_CI + 1) + cl] = s0 + s1;
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) tile[kl * tstride + tap * (WR_CI + 1) + cl] = s0[tap] + s1[tap];
+  } else {
+    for (int tap = 0; tap < taps; ++tap) {
+      float s0 = 0.f, s1 = 0.f;
+      if (ci < Ci) {
+        const float* p = ws + ((size_t)co * taps + tap) * Ci + ci;
+        int k = kl;
+        for (; k + KL < splits; k += 2 * KL) {
+          s0 += p[(size_t)k * total];
+          s1 += p[(size_t)(k + KL) * total];
+        }
+        if (k < splits) s0 += p[(size_t)k * total];
+      }
+      tile[kl * tstride + tap * (WR_CI + 1) + cl] = s0 + s1;
+    }
   }
   __syncthreads();
   const int n = taps * WR_CI;
@@ -466,8 +496,12 @@ extern "C" int mi355_conv2d_wgrad_reduce(const float* ws, int splits, float* dw,
   if (KL > 32) KL = 32;
   if (KL > splits) KL = splits;
   if (KL < 1) KL = 1;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(Co * ciTiles), dim3(WR_CI * KL), KL * taps * (WR_CI + 1) * sizeof(float), (hipStream_t)s,
-                     ws, splits, dw, Co, Ci, Ci_real, taps, transposed, beta, KL);
+  const dim3 grid(Co * ciTiles), block(WR_CI * KL);
+  const size_t lds = KL * taps * (WR_CI + 1) * sizeof(float);
+  if (taps == 9)          // (same sums in the same order as the run-time loop: two chains per thread, split k before k + KL)
+    hipLaunchKernelGGL(wgrad_reduce_kernel<9>, grid, block, lds, (hipStream_t)s, ws, splits, dw, Co, Ci, Ci_real, taps, transposed, beta, KL);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel<0>, grid, block, lds, (hipStream_t)s, ws, splits, dw, Co, Ci, Ci_real, taps, transposed, beta, KL);
   MI355_LAUNCH_CHECK();
   return MI355_OK;
 }

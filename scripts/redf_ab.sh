@@ -1,8 +1,6 @@
 #!/bin/bash
+# rows in flight per thread in the BatchNorm backward apply pass (A/B builds), C3 and C4
 R=$PWD
-bash scripts/env_sweep.sh r04i_redw "" "MI355_LIB=$R/ab/redw512.so" "MI355_LIB=$R/ab/redw1024.so"
-for v in "" "MI355_LIB=$R/ab/redw512.so" "MI355_LIB=$R/ab/redw1024.so"; do
-  echo "== [${v:-defaults}]" >> gpurun_out/r04i_redw.txt
-  env $v python bench.py --steps 10 --warmup 3 --no-cpu-baseline --kernel-table 2>&1 >/dev/null | grep -E "bn_bwd_reduce|sum of plan" >> gpurun_out/r04i_redw.txt
-done
-cat gpurun_out/r04i_redw.txt
+V=("" "MI355_LIB=$R/ab/applyf8.so" "MI355_LIB=$R/ab/applyf6.so" "MI355_LIB=$R/ab/applyf2.so")
+bash scripts/env_sweep.sh r04i_applyf "${V[@]}"
+BENCH_ARGS="--model R2AttU_Net --batch 16" bash scripts/env_sweep.sh r04i_applyf_c4 "${V[@]}"

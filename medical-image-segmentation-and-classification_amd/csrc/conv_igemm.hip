@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   const int dmask = (1 << a.dshift) - 1;
 
   uint4 ra[A_IT], rb[B_IT];
+  bool a_ok[A_IT];
   auto load_tile = [&](int kh, int kw, int c0) {
     const int dh = kh * a.kmul, dw = kw * a.kmul;
 #pragma unroll
@@ -121,12 +122,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
       ok = ok && (unsigned)th < (unsigned)a.Hlog && (unsigned)tw < (unsigned)a.Wlog;
       th >>= a.up;
       tw >>= a.up;
-      if (ok) {
-        const T* p = in + ((size_t)(a_nb[i] + th) * a.Wi + tw) * a.ldi + c0 + chunk * EPC;
-        ra[i] = *reinterpret_cast<const uint4*>(p);
-      } else {
-        ra[i] = make_uint4(0, 0, 0, 0);
-      }
+      // the load is issued from a CLAMPED pixel whatever `ok` says and masked afterwards: under `if (ok)` hipcc branches around it
+      // and waits for it on the spot (s_waitcnt vmcnt(0) per row: A_IT dependent round trips per K tile instead of one)
+      const T* p = in + ((size_t)(a_nb[i] + (ok ? th : 0)) * a.Wi + (ok ? tw : 0)) * a.ldi + c0 + chunk * EPC;
+      ra[i] = *reinterpret_cast<const uint4*>(p);
+      a_ok[i] = ok;
     }
     const int tap = kh * a.KW + kw;
 #pragma unroll
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int row = srow + i * RPP;
-      *reinterpret_cast<uint4*>(la + row * P + swz(row, chunk)) = ra[i];
+      *reinterpret_cast<uint4*>(la + row * P + swz(row, chunk)) = a_ok[i] ? ra[i] : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
@@ -693,7 +693,7 @@ extern "C" int mi355_conv2d_igemm(const void* in, const void* wk, const float* b
   a.Wlog = up ? 2 * Wi : Wi;
   hipStream_t st = (hipStream_t)s;
   const bool k64 = Ci % 64 == 0;
-  if (esz == 4) return launch_bn<float, 16>(a, st);
+  if (esz == 4) return launch_bn<float, 16>(a, st);      // (32-channel K tiles measured: +2 % on 128-wide tiles, -13 % on 64-wide ones)
   return dispatch_dtype(dtype, "conv2d_igemm", [&](auto tag) -> int {
     using T = decltype(tag);
     if constexpr (sizeof(T) == 2) {

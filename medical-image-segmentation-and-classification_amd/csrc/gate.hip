@@ -124,12 +124,14 @@ extern "C" int mi355_rowdot_fwd(const void* x, int ldx, const float* w, const fl
 }
 
 // dx[m][c] = dz[m]*w[c]*(mask ? x[m][c] > 0 : 1);  partial: q0 = sum_m dz[m]*x[m][c], q1 = sum_m dz[m]
-template <typename T> struct RowdotBwdOp {
+// ACC (dx accumulates: a further output channel of a multi-channel head) is compile-time and its operand part of the fetch: a load
+// under a run-time condition inside finish() would be waited for on the spot (common.hpp, ld16_pol)
+template <typename T, bool ACC = false> struct RowdotBwdOp {
   static constexpr int NQ = 2;
   static constexpr bool WRITES = true;
   typedef float Acc;
   static constexpr int EPC = 16 / (int)sizeof(T);
-  const float* dz; const T* x; int ldx; const float* w; T* dx; int lddx; int mask; int hw; int K; int acc_dx;
+  const float* dz; const T* x; int ldx; const float* w; T* dx; int lddx; int mask; int hw; int K;
   float wr[EPC];
   __device__ void load_cols(int c0) {
 #pragma unroll
@@ -137,9 +139,18 @@ template <typename T> struct RowdotBwdOp {
   }
   static constexpr int FETCH_ROWS = 4;        // (rowred.hpp: rows fetched before any is finished)
   static constexpr int MAX_WGS = 1024;        // one fp32 + one 2-byte stream per row: more workgroups than the BN reductions' one per CU
-  struct In { Vec16<T> v; float d; };
+  struct In { Vec16<T> v, old; float d; };
   __device__ In fetch(size_t row, int c0) const {
-    return In{ld16<T>(x + row * ldx + c0), dz[K == 1 ? row : row + (row / hw) * (size_t)(K - 1) * hw]};
+    In in;
+    in.v = ld16<T>(x + row * ldx + c0);
+    if constexpr (ACC) in.old = ld16<T>(dx + row * lddx + c0);
+    in.d = dz[K == 1 ? row : row + (row / hw) * (size_t)(K - 1) * hw];
+    return in;
+  }
+  __device__ void pin(In& in) const {
+    pin16(in.v);
+    if constexpr (ACC) pin16(in.old);
+    asm volatile("" : "+v"(in.d) : : "memory");
   }
   __device__ void finish(const In& in, size_t row, int c0, Acc (&acc)[NQ][EPC]) const {
     const float d = in.d;
@@ -151,10 +162,9 @@ template <typename T> struct RowdotBwdOp {
       acc[1][e] += d;
       o.v[e] = from_f32<T>((mask && !(xv > 0.f)) ? 0.f : d * wr[e]);
     }
-    if (dx && acc_dx) {                       // a further output channel of a multi-channel head adds its share
-      const Vec16<T> old = ld16<T>(dx + row * lddx + c0);
+    if constexpr (ACC) {                      // a further output channel of a multi-channel head adds its share
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) o.v[e] = from_f32<T>(to_f32<T>(old.v[e]) + to_f32<T>(o.v[e]));
+      for (int e = 0; e < EPC; ++e) o.v[e] = from_f32<T>(to_f32<T>(in.old.v[e]) + to_f32<T>(o.v[e]));
     }
     if (dx) st16<T>(dx + row * lddx + c0, o);
   }
@@ -167,7 +177,11 @@ extern "C" int mi355_rowdot_bwd(const float* dz, const void* x, int ldx, const f
   MI355_CHECK_ARG(K >= 1 && (K == 1 || (HW > 0 && M % HW == 0)), "rowdot_bwd: K=%d planes need HW | M", K);
   return dispatch_dtype(dtype, "rowdot_bwd", [&](auto tag) {
     using T = decltype(tag);
-    RowdotBwdOp<T> op{dz, (const T*)x, ldx, w, (T*)dx, lddx, relu_mask, HW, K, accumulate};
+    if (dx && accumulate) {
+      RowdotBwdOp<T, true> op{dz, (const T*)x, ldx, w, (T*)dx, lddx, relu_mask, HW, K};
+      return rowred_launch<T>(op, M, C, partial, (hipStream_t)s);
+    }
+    RowdotBwdOp<T, false> op{dz, (const T*)x, ldx, w, (T*)dx, lddx, relu_mask, HW, K};
     return rowred_launch<T>(op, M, C, partial, (hipStream_t)s);
   });
 }

@@ -38,11 +38,12 @@ def kernels(tmp_path_factory):
                          for k in ("private_segment_fixed_size", "vgpr_count", "vgpr_spill_count", "sgpr_spill_count",
                                    "max_flat_workgroup_size", "group_segment_fixed_size")}
     assert len(out) > 150, len(out)
+    out["__dir__"] = str(d)
     return out
 
 
 def _pick(kernels, pattern):
-    hit = {k: v for k, v in kernels.items() if re.search(pattern, k)}
+    hit = {k: v for k, v in kernels.items() if k != "__dir__" and re.search(pattern, k)}
     assert hit, pattern
     return hit
 
@@ -83,3 +84,47 @@ def test_eight_wave_weight_gradient_fits_two_waves_per_simd(kernels):
     for name, k in _pick(kernels, r"wgrad3x3_halo8_kernel").items():
         assert k["max_flat_workgroup_size"] == 512 and k["vgpr_count"] <= 256, (name, k)
     assert len(_pick(kernels, r"wgrad3x3_halo8_kernel")) == 4          # bf16 / fp16 x (64-pixel segments, 32-pixel image pairs)
+
+
+STREAMING = (r"rowred_kernel|rowmap_kernel|bn_act_pool2_kernel|pack_im2col3_kernel|pack_weight_batched_kernel|pack_nchw_kernel|"
+             r"gate_psi_fwd_kernel|gate_mul_bwd_kernel|wgrad_reduce_kernel")
+
+
+def test_streaming_kernels_do_not_wait_for_a_load_on_the_spot(kernels):
+    """The guarded-load trap ("Round 4, second half"): hipcc branches around a load that sits under a run-time
+    condition and waits for it right there (s_waitcnt vmcnt(0)), which turns a loop written to keep N loads in flight into N dependent
+    round trips.  Read from the disassembly of the shipped code objects: in every HBM-bound kernel, at most two loads are followed
+    within two instructions by a full wait (a remainder loop's single row); the round-3 library had 8 in the BatchNorm backward apply
+    pass, 4-8 in the reduce passes, 27 in the stem's im2col pack."""
+    d = kernels["__dir__"]
+    bad, seen = [], 0
+    for f in sorted(os.listdir(d)):
+        if "amdgcn" not in f:
+            continue
+        dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", os.path.join(d, f)], check=True, capture_output=True, text=True).stdout
+        cur, n_load, n_trap, last, idx = None, 0, 0, -10, 0
+
+        def close():
+            nonlocal seen
+            if cur is not None and re.search(STREAMING, cur):
+                seen += 1
+                if n_trap > 2:
+                    bad.append((cur, n_trap, n_load))
+        for line in dis.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                close()
+                cur, n_load, n_trap, last, idx = m.group(1), 0, 0, -10, 0
+                continue
+            t = line.strip().split()
+            if cur is None or not line.startswith("\t") or not t:
+                continue
+            idx += 1
+            if t[0].startswith(("global_load", "buffer_load")):
+                n_load += 1
+                last = idx
+            elif t[0] == "s_waitcnt" and "vmcnt(0)" in line and idx - last <= 2:
+                n_trap += 1
+        close()
+    assert seen >= 100, seen                     # the pattern still finds the kernels it is about
+    assert not bad, bad

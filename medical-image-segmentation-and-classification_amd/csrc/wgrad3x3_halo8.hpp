@@ -52,7 +52,29 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_halo8_kernel(const Wgrad3Args
   const int ciTiles = (a.Ci + 63) / 64;
   const int bid = xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
   const int bx = bid % gridDim.x, by = bid / gridDim.x;
-  const int co0 = (bx / ciTiles) * 64, ci0 = (bx % ciTiles) * 64;
+  // Tile order inside one row band: an XCD owns Q = grid / 8 consecutive `bid`s (xcd_tile), i.e. Q tiles of one band when the
+  // band has at least Q.  As a BH x BW block of the (Co / 64) x (Ci / 64) tile grid they fetch BH / coT of dY and BW / ciT of X
+  // through that XCD's L2 — least for the squarest block (1024 -> 512 @32²: 4 x 4 instead of 1 x 16 = a quarter of X + half of dY
+  // instead of all of X + an eighth of dY).  -DWG8_ROW_TILES: row-major tiles as before (A/B).
+  int tco = bx / ciTiles, tci = bx % ciTiles;
+#ifndef WG8_ROW_TILES
+  {
+    const int coT = gridDim.x / ciTiles, Q = (int)(gridDim.x * gridDim.y) >> 3;
+    if (Q >= 4 && (int)gridDim.x % Q == 0 && ((gridDim.x * gridDim.y) & 7) == 0) {
+      int BW = 0, best = 1 << 30;
+      for (int w = 1; w <= Q; w <<= 1) {
+        const int h = Q / w;
+        if (w * h == Q && ciTiles % w == 0 && coT % h == 0 && w + h < best) { best = w + h; BW = w; }
+      }
+      if (BW) {
+        const int BH = Q / BW, blk = bx / Q, j = bx % Q, bpr = ciTiles / BW;
+        tco = (blk / bpr) * BH + j / BW;
+        tci = (blk % bpr) * BW + j % BW;
+      }
+    }
+  }
+#endif
+  const int co0 = tco * 64, ci0 = tci * 64;
   auto swz = [](int px) { return (((px >> 1) & 1) | (((px >> 3) & 1) << 1)) << 1; };     // XOR on the 16-B chunk index
 
   const int lpx = lane >> 3, slot = lane & 7;       // DMA: a 1-KiB piece = 8 pixels x 128 B; lane -> (pixel, 16-B slot)

@@ -109,3 +109,61 @@ def test_block_bf16_close_to_reference(tag):
     ref = z[tag + "/out"]
     lim = 6e-2 if tag in ("Recurrent_block", "RRCNN_block") else 3e-2     # 6 / 12 stacked bf16 conv+BN
     assert np.abs(out.cpu().numpy() - ref).max() < lim * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("t", [2, 7, 10])
+def test_recurrent_block_deferred_gradient_sum_any_number_of_applications(t):
+    """Recurrent_block (R2AttU_Net.py:29-45) applied t + 1 times: the block input's gradient is the sum of t incoming gradients plus
+    the first convolution's data gradient.  With DEFER_POST the BatchNorm apply passes leave them pending and
+    mi355_bn_bwd_apply_post4 adds up to four at a time (t = 7: a flush in the middle and one at the end; t = 10: two in the middle),
+    without it every pass read-modify-writes the gradient.  Same terms, another order: fp32 results agree to summation-order
+    rounding; the forward is untouched (bit-identical)."""
+    from mi355 import graph
+    from mi355.engine import Net
+    from models.segmentation_models import _blocks as B
+    args = bc.CASES["Recurrent_block"][0]
+    x = _net_input("Recurrent_block").to(DEV)
+    res = {}
+    saved = graph.DEFER_POST
+    try:
+        for defer in (True, False):
+            graph.DEFER_POST = defer
+            blk = B.Recurrent_block(args[0], args[1], t=t)
+            blk.load_state_dict(bc.fill("Recurrent_block", blk.state_dict()))
+
+            class BlockNet(Net):
+                def __init__(self):
+                    super().__init__()
+                    self.block = blk
+
+                def build(self, g, xx):
+                    g.want_input_grad(xx)
+                    g.tensor_output(self.block.lower(g, xx))
+
+            net = BlockNet()
+            net.compute_dtype = torch.float32
+            net = net.to(DEV).train()
+            out = net(x)
+            w = bc.out_weight("Recurrent_block", tuple(out.shape))
+            (out * w.to(DEV)).sum().backward()
+            torch.cuda.synchronize()
+            plan = out._mi355_plan
+            names = [l.name for l in plan.bwd]
+            res[defer] = (out.detach().cpu(), plan.input_grad.view(x.shape).cpu().clone(),
+                          {k: p.grad.detach().cpu().clone() for k, p in net.block.named_parameters()}, names)
+    finally:
+        graph.DEFER_POST = saved
+    on, off = res[True], res[False]
+    want, pend = 0, 0                      # Builder._bn_bwd's rule, replayed: t applications add the block input
+    for i in range(1, t + 1):
+        if i < t and pend < 4:
+            pend += 1
+        else:
+            want, pend = want + (pend > 0), 0
+    assert on[3].count("mi355_bn_bwd_apply_post4") == want and want >= 1
+    assert "mi355_bn_bwd_apply_post4" not in off[3]
+    assert torch.equal(on[0], off[0])
+    assert float((on[1] - off[1]).abs().max()) <= 2e-5 * float(off[1].abs().max())
+    gmax = max(float(g.abs().max()) for g in off[2].values())
+    for k, g in off[2].items():
+        assert float((on[2][k] - g).abs().max()) <= 2e-5 * (float(g.abs().max()) + 1e-3 * gmax), k

@@ -188,3 +188,64 @@ def test_trainer_script_under_the_launcher_two_ranks(tmp_path):
     assert len(lines) == 2, r.stdout                       # one line per epoch: rank 1 printed nothing
     assert r.stdout.count("===== SUMMARY =====") == 1 and "best val loss" in r.stdout
     assert os.listdir(str(tmp_path / "w" / "segmentation_models")) == ["attentionunet_best_loss.pt"]
+
+
+def _cls_worker(rank, world, port, save_dir, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    _paths()
+    from utils.helpers import get_class_model, train
+    torch.manual_seed(rank)                                # rank-dependent initialisation: train() starts from rank 0's
+    m, head = get_class_model("resnet18")
+    m.compute_dtype = torch.bfloat16
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from torch.utils.data import DataLoader, TensorDataset
+        g = torch.Generator().manual_seed(3)
+        xt, yt = torch.randn(24, 3, 64, 64, generator=g), torch.randint(0, 3, (24,), generator=g)
+        xv, yv = torch.randn(12, 3, 64, 64, generator=g), torch.randint(0, 3, (12,), generator=g)
+        tr = DataLoader(TensorDataset(xt, yt), batch_size=4, shuffle=False)
+        va = DataLoader(TensorDataset(xv, yv), batch_size=4, shuffle=False)
+        buf = io.StringIO()
+        with redirect_stdout(buf):
+            best = train(m, tr, va, DEV, 7, 1e-4, "resnet18", save_dir, seg=False, cls_head_name=head)
+        torch.cuda.synchronize()
+        sd = {k: v.detach().float().cpu().numpy() for k, v in m.state_dict().items()}
+        frozen = [k for k, p in m.named_parameters() if not p.requires_grad]
+        q.put((rank, "ok", best, buf.getvalue(), sd, frozen))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "fail", traceback.format_exc(), "", None, None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_train_world2_classification_crosses_the_stage_switch(tmp_path):
+    """The two-stage classifier protocol (helpers.py:267-283 head only for five epochs, :296-309 everything from epoch 6) under data
+    parallelism: stage 1's plan has gradients for the head alone (two small buckets), stage 2 re-plans with every parameter — the
+    bucket schedule, inv_scale and the buffer sync must follow.  Dropout masks differ per rank, so there is no single-process
+    emulation to compare with; the invariants are: both ranks end with bit-identical parameters AND BatchNorm buffers, the same
+    best accuracy, nothing left frozen, rank 1 silent, one checkpoint written by rank 0, both stage banners printed once."""
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    save_dir = str(tmp_path / "c")
+    port = _free_port()
+    procs = [ctx.Process(target=_cls_worker, args=(r, 2, port, save_dir, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status, info, *_ in res:
+        assert status == "ok", f"rank {rank}: {info}"
+    (_, _, best0, log0, sd0, fr0), (_, _, best1, log1, sd1, fr1) = res
+    assert best0 == best1 and 0.0 <= best0 <= 100.0          # (accuracy in percent, helpers.py:363)
+    assert set(sd0) == set(sd1)
+    for k in sd0:
+        assert np.array_equal(sd0[k], sd1[k]), k
+    assert fr0 == [] and fr1 == []
+    assert log1 == ""
+    assert log0.count("--- STAGE 1") == 1 and log0.count("--- STAGE 2") == 1
+    assert len([ln for ln in log0.splitlines() if ln.startswith("[resnet18] Ep")]) == 7
+    assert os.listdir(save_dir) == ["resnet18_best_acc.pt"]

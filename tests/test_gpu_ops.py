@@ -107,6 +107,50 @@ def test_bn_backward(dtype, act, with_res, shape):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("n_ex,post_acc,with_y", [(1, 0, False), (4, 1, False), (3, 1, True), (2, 0, True)])
+def test_bn_backward_apply_with_the_earlier_gradients_summed(dtype, n_ex, post_acc, with_y):
+    """mi355_bn_bwd_apply_post4 (the recurrent block's last application, R2AttU_Net.py:41-44): dx bit-identical to mi355_bn_bwd_apply
+    on the same operands, dpost = round(dy [+ dpost] + ex0 + .. ) summed in fp32 in that order and rounded once — also with the
+    activated tensor as the mask source (`y`), fewer than four extras, 3 x 37 x 41 rows (ragged batches) and 96 channels."""
+    n, c, h, w = 3, 96, 37, 41
+    g = torch.Generator().manual_seed(11 + n_ex)
+    m = n * h * w
+    code = DTYPE_CODE[dtype]
+    x = q(torch.randn(n, c, h, w, generator=g) * 1.5 + 0.3, dtype)
+    dy = q(torch.randn(n, c, h, w, generator=g), dtype)
+    ex = [q(torch.randn(n, c, h, w, generator=g), dtype) for _ in range(n_ex)]
+    old = q(torch.randn(n, c, h, w, generator=g), dtype)
+    gamma = torch.rand(c, generator=g) + 0.5; beta = torch.randn(c, generator=g)
+    mu = x.mean((0, 2, 3)); isd = 1 / torch.sqrt(x.var((0, 2, 3), unbiased=False) + 1e-5)
+    sc, sh = gamma * isd, beta - mu * gamma * isd
+    y = q(F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)), dtype)
+    xd, dyd, yd = to_nhwc(x, dtype), to_nhwc(dy, dtype), to_nhwc(y, dtype)
+    exd = [to_nhwc(e, dtype) for e in ex] + [None] * (4 - n_ex)
+    nb, part = _partials(m, c)
+    ya = yd if with_y else None
+    lib.mi355_bn_bwd_reduce(dyd, c, ya, c, xd, c, dev(mu), dev(isd), dev(sc), dev(sh), part, m, c, 1, code)
+    sums = torch.empty(2 * c, device=DEV)
+    lib.mi355_bn_bwd_finalize(part, nb, c, sums, None, None, 0.0)
+    dx_ref, dx = torch.empty_like(xd), torch.empty_like(xd)
+    lib.mi355_bn_bwd_apply(dyd, c, ya, c, xd, c, dev(gamma), dev(mu), dev(isd), dev(sc), dev(sh), sums, dx_ref, c, None, 0, None, 0, 0,
+                           None, m, c, 1, code)
+    dpost = to_nhwc(old, dtype)
+    lib.mi355_bn_bwd_apply_post4(dyd, c, ya, c, xd, c, dev(gamma), dev(mu), dev(isd), dev(sc), dev(sh), sums, dx, c, dpost, c, post_acc,
+                                 exd[0], exd[1], exd[2], exd[3], c, m, c, 1, code)
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx_ref)
+    want = dy.float()
+    if post_acc:
+        want = want + old.float()
+    for e in ex:
+        want = want + e.float()
+    assert torch.equal(from_nhwc(dpost).float(), want.to(dtype).float())
+    with pytest.raises(RuntimeError):           # a gap in the earlier gradients (ex1 without ex0 is refused at the entry point)
+        lib.mi355_bn_bwd_apply_post4(dyd, c, ya, c, xd, c, dev(gamma), dev(mu), dev(isd), dev(sc), dev(sh), sums, dx, c, dpost, c, 0,
+                                     None, exd[0], None, None, c, m, c, 1, code)
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_bn_act_two_operands_and_eval_coeffs(dtype):
     n, c, h, w = 2, 32, 6, 6
     g = torch.Generator().manual_seed(2)

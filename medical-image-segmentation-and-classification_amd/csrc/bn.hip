@@ -449,7 +449,7 @@ template <typename T, bool HASY = false, bool KEEP = true> struct BnBwdReduceOp 
       float gg = to_f32<T>(in.g.v[e]);
       const float xf = to_f32<T>(in.xv.v[e]);
       if (act) {
-        const bool on = HASY ? (to_f32<T>(in.yv.v[e]) > 0.f) : (xf * ms[e] + mt[e] > 0.f);
+        const bool on = HASY ? (to_f32<T>(in.yv.v[e]) > 0.f) : (__builtin_fmaf(xf, ms[e], mt[e]) > 0.f);
         if (!on) gg = 0.f;
       }
       acc[0][e] += gg;
@@ -595,11 +595,11 @@ template <typename T, int NEX = 0, bool HASY = false, bool PACC = false, bool KE
       float gg = to_f32<T>(in.g.v[e]);
       const float xf = to_f32<T>(in.xv.v[e]);
       if (act) {
-        const bool on = HASY ? (to_f32<T>(in.yv.v[e]) > 0.f) : (xf * ms[e] + mt[e] > 0.f);
+        const bool on = HASY ? (to_f32<T>(in.yv.v[e]) > 0.f) : (__builtin_fmaf(xf, ms[e], mt[e]) > 0.f);
         if (!on) gg = 0.f;
       }
       const float xh = (xf - mu[e]) * is[e];
-      const float d = gi[e] * (gg - k0[e] - xh * k1[e]);
+      const float d = bn_dx(gi[e], gg, k0[e], xh, k1[e]);
       o.v[e] = from_f32<T>(d);
       r.v[e] = from_f32<T>(gg);
       acc[0][e] += d;
@@ -783,7 +783,7 @@ template <typename T, bool HASDY, bool KEEP = true> struct BnBwdApplyPool2Op : B
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         const float xh = (to_f32<T>(p.xv[b].v[e]) - this->mu[e]) * this->is[e];
-        const float d = gi[e] * (g[b] - k0[e] - xh * k1[e]);
+        const float d = bn_dx(gi[e], g[b], k0[e], xh, k1[e]);
         o[b].v[e] = from_f32<T>(d);
         acc[0][e] += d;
       }

@@ -181,3 +181,8 @@ template <typename F> static inline int dispatch_dtype(int dtype, const char* wh
   }
 }
 static inline bool dtype_is_2byte(int dtype) { return dtype == MI355_BF16 || dtype == MI355_F16; }
+
+// dx of a train-mode BatchNorm, gi * (g - k0 - xhat * k1), with the fused multiply-add written out: every kernel that evaluates it
+// (plain / pool-aware / gate / post4 apply passes, each in several instantiations) then rounds the same way — left to the compiler,
+// the contraction differed between two instantiations of the same op and the results in the last bit (seen in fp16 outputs).
+__device__ __forceinline__ float bn_dx(float gi, float g, float k0, float xhat, float k1) { return gi * __builtin_fmaf(-xhat, k1, g - k0); }

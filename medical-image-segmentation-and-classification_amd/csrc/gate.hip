@@ -378,10 +378,10 @@ template <typename T, bool TWO, bool KEEP = true> struct GateBnBwdApplyOp : Gate
     for (int e = 0; e < EPC; ++e) {
       const float dp = this->dpsi(in, e, this->act(in, e));
       const float hg = (to_f32<T>(in.gv.v[e]) - this->mg[e]) * this->ig[e];
-      og.v[e] = from_f32<T>(gg[e] * (dp - kg0[e] - hg * kg1[e]));
+      og.v[e] = from_f32<T>(bn_dx(gg[e], dp, kg0[e], hg, kg1[e]));
       if constexpr (TWO) {
         const float hx = (to_f32<T>(in.xv.v[e]) - this->mx[e]) * this->ix[e];
-        ox.v[e] = from_f32<T>(gx[e] * (dp - kx0[e] - hx * kx1[e]));
+        ox.v[e] = from_f32<T>(bn_dx(gx[e], dp, kx0[e], hx, kx1[e]));
       }
     }
     st16<T>(dg + row * lddg + c0, og);

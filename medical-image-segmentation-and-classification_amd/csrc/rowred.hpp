@@ -114,7 +114,34 @@ __global__ __launch_bounds__(256) void rowred_kernel(Op op, RowRedGeom g, float*
       // each own a far-apart contiguous band were measured slower: see DESIGN.md, streaming kernels).
       constexpr int B = Op::FETCH_ROWS;
       const long long st = (long long)gridDim.x * g.rp * B;
-      for (long long r = (long long)blockIdx.x * g.rp * B + ty; r < g.M; r += st) {
+      long long r = (long long)blockIdx.x * g.rp * B + ty;
+#ifndef RR_NO_RING
+      // The B rows in flight are a RING: as soon as row b of this batch has been waited for, row b of the workgroup's NEXT batch
+      // is requested into the same slot, in front of row b's arithmetic — the loads never drain between batches.  The last
+      // batch requests its own rows again (a clamped, unconditional address: a load under `if (more)` would be waited for on the
+      // spot) and ignores them.
+      if (r + (long long)(B - 1) * g.rp < g.M) {
+        typename Op::In in[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) in[b] = op.fetch((size_t)(r + (long long)b * g.rp), c0);
+        for (;;) {
+          const long long rn = r + st;
+          const bool more = rn + (long long)(B - 1) * g.rp < g.M;
+          const long long rf = more ? rn : r;
+#pragma unroll
+          for (int b = 0; b < B; ++b) {
+            if constexpr (has_pin<Op, typename Op::In>::value) op.pin(in[b]);      // (waits for row b only; the rest of the ring stays in flight)
+            const typename Op::In cur = in[b];
+            in[b] = op.fetch((size_t)(rf + (long long)b * g.rp), c0);
+            op.finish(cur, (size_t)(r + (long long)b * g.rp), c0, acc);
+          }
+          r = rn;
+          if (!more) break;
+        }
+      }
+      for (long long q = r; q < g.M; q += g.rp) op.finish(op.fetch((size_t)q, c0), (size_t)q, c0, acc);      // the rows behind the last whole batch
+#else
+      for (; r < g.M; r += st) {
         if (r + (long long)(B - 1) * g.rp < g.M) {
           typename Op::In in[B];
 #pragma unroll
@@ -131,6 +158,7 @@ __global__ __launch_bounds__(256) void rowred_kernel(Op op, RowRedGeom g, float*
           for (long long q = r; q < g.M; q += g.rp) op.finish(op.fetch((size_t)q, c0), (size_t)q, c0, acc);
         }
       }
+#endif
     } else if constexpr (!Op::WRITES && sizeof(typename Op::Acc) == 4) {
       // read-only reductions: two rows per trip keep twice the bytes in flight (+5 % on bn_bwd_reduce; ops that also
       // store — bn_bwd_apply — were measured slower with it)

@@ -101,12 +101,33 @@ __global__ __launch_bounds__(256) void rowred_kernel(Op op, RowRedGeom g, float*
       // per CU were measured within noise of this loop: profiles/r03c_ab_poolbwd.txt)
       constexpr int B = Op::BATCH_ROWS;
       const long long st = (long long)gridDim.x * g.rp * B;
-      for (long long r = (long long)blockIdx.x * g.rp * B; r < g.M; r += st) {
+      long long r = (long long)blockIdx.x * g.rp * B;
+#ifndef RR_NO_RING
+      // the NEXT batch is requested as soon as this one has landed, in front of its arithmetic (these ops recompute activations
+      // and window maxima: a microsecond of VALU work per batch during which nothing was in flight); the last trip requests its
+      // own batch again — a clamped address, not a load under a condition — and ignores it
+      if (r < g.M) {
+        typename Op::Px p;
+        op.fetch(r, ty, c0, p);
+        for (;;) {
+          const long long rn = r + st;
+          const bool more = rn < g.M;
+          if constexpr (has_pin<Op, typename Op::Px>::value) op.pin(p);
+          typename Op::Px cur = p;
+          op.fetch(more ? rn : r, ty, c0, p);
+          op.finish(cur, ty, c0, acc);
+          r = rn;
+          if (!more) break;
+        }
+      }
+#else
+      for (; r < g.M; r += st) {
         typename Op::Px p;
         op.fetch(r, ty, c0, p);
         if constexpr (has_pin<Op, typename Op::Px>::value) op.pin(p);      // (all loads of the batch issued before the arithmetic: see has_pin)
         op.finish(p, ty, c0, acc);
       }
+#endif
     } else if constexpr (has_fetch<Op>::value) {
       // ops that also store: the compiler may not move a load above the previous row's store (the tensors can alias), so
       // the rows of a trip are fetched explicitly before any of them is finished — FETCH_ROWS x the bytes in flight

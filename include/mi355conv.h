@@ -111,6 +111,9 @@ int mi355_conv2d_igemm_variant_n(int N, int Hi, int Wi, int Ci, int Ho, int Wo, 
  * (per WORKGROUP for the streaming pointwise kernel) it dispatches to, stats[(b*2+0)*Co + c] = sum and stats[(b*2+1)*Co + c] = sum of squares of the
  * (rounded) outputs — the same partial layout mi355_bn_finalize consumes.  The number of tile rows is
  * mi355_conv2d_igemm_stat_rows(...) (0 = not available for this shape/dtype: use mi355_bn_stats). */
+/* Output-channel tile (128 / 64 / 32) of the LDS-DMA ring kernel (variant 1) for N x Ho x Wo output rows: the widest that divides
+ * Co unless its grid would leave most of the chip idle (bench.py's kernel names). */
+int mi355_conv2d_igemm_dma_tile(int N, int Ho, int Wo, int Ci, int Co);
 int mi355_conv2d_igemm_stat_rows(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW,
                                  int mul, int kmul, int off, int div, int up, int dtype);
 

@@ -606,6 +606,21 @@ static IgemmVariant resolve_variant(IgemmVariant v, int N, int Ho, int Wo, int C
   return grid * 100 >= rounds * cus * fill ? IG_HALO_PP128 : IG_HALO_8x32;     // >= 80 % of the last round filled
 }
 
+// Output-channel tile of the LDS-DMA ring kernel: the widest that divides Co — unless its grid leaves most of the chip idle (the
+// frozen ResNet-50 encoder's 8 x 8 and 16 x 16 layers at batch 32: M = 2048 rows x 512 channels = 64 workgroups of 128 x 128), then
+// the next narrower one (twice / four times the workgroups).  MI355_DMA_SMALLGRID=0: always the widest (A/B).
+static int dma_tile_n(long long M, int Ci, int Co) {
+  static const int small = getenv("MI355_DMA_SMALLGRID") ? atoi(getenv("MI355_DMA_SMALLGRID")) : 1;
+  const long long rows = (M + 127) / 128;
+  int bn = Co % 128 == 0 ? 128 : (Co % 64 == 0 ? 64 : 32);
+  if (small) {
+    const int cus = device_cus();
+    if (bn == 128 && rows * (Co / 128) * 2 <= cus) bn = 64;                       // at most half a round of workgroups
+    if (bn == 64 && Ci % 64 == 0 && rows * (Co / 64) * 2 <= cus) bn = 32;         // (the 32-wide instance runs 64-channel K tiles)
+  }
+  return bn;
+}
+
 static bool halo_family(IgemmVariant v) {
   return v == IG_HALO_8x32 || v == IG_HALO_16x16 || v == IG_HALO_PP || v == IG_HALO_PP128 || v == IG_WS64 || v == IG_WS128;
 }
@@ -630,6 +645,9 @@ extern "C" int mi355_conv2d_igemm_variant_n(int N, int Hi, int Wi, int Ci, int H
                                             int off, int div, int up, int dtype) {
   return (int)final_variant(N, Hi, Wi, Ci, Ho, Wo, Co, KH, KW, mul, kmul, off, div, up, dtype);
 }
+
+/* output-channel tile (128 / 64 / 32) the LDS-DMA ring kernel (variant 1) runs for N x Ho x Wo rows, Ci -> Co channels */
+extern "C" int mi355_conv2d_igemm_dma_tile(int N, int Ho, int Wo, int Ci, int Co) { return dma_tile_n((long long)N * Ho * Wo, Ci, Co); }
 
 extern "C" int mi355_conv2d_igemm_stat_rows(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int mul,
                                             int kmul, int off, int div, int up, int dtype) {
@@ -709,9 +727,11 @@ extern "C" int mi355_conv2d_igemm(const void* in, const void* wk, const float* b
         case IG_DMA:
           // measured on MI355X (AttentionUNet shapes): the 2-deep BK=64 ring (2 workgroups/CU) wins for 128-wide tiles,
           // the 3-deep BK=32 ring (3-4 workgroups/CU) for 64-wide tiles and for Ci % 64 != 0
-          if (Co % 128 == 0) return k64 ? launch_dma<T, 128, 64, 2>(a, st) : launch_dma<T, 128, 32, 3>(a, st);
-          if (Co % 64 == 0) return launch_dma<T, 64, 32, 3>(a, st);
-          return launch_dma<T, 32, 64, 3>(a, st);
+          switch (dma_tile_n(a.M, Ci, Co)) {
+            case 128: return k64 ? launch_dma<T, 128, 64, 2>(a, st) : launch_dma<T, 128, 32, 3>(a, st);
+            case 64: return launch_dma<T, 64, 32, 3>(a, st);
+            default: return launch_dma<T, 32, 64, 3>(a, st);
+          }
         default: return k64 ? launch_bn<T, 64>(a, st) : launch_bn<T, 32>(a, st);
       }
     }

@@ -660,6 +660,7 @@ class Builder:
         if v == 0:
             return f"conv_igemm_kernel<bf16,{bn},{64 if k64 else 32}>"
         if v == 1:
+            bn = lib.mi355_conv2d_igemm_dma_tile(N, Ho, Wo, ci, co)      # (narrower than Co allows when the grid would be small)
             if bn == 128:
                 return "conv_igemm_dma_kernel<128,64,2>" if k64 else "conv_igemm_dma_kernel<128,32,3>"
             return "conv_igemm_dma_kernel<64,32,3>" if bn == 64 else "conv_igemm_dma_kernel<32,64,3>"

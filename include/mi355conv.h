@@ -114,6 +114,7 @@ int mi355_conv2d_igemm_variant_n(int N, int Hi, int Wi, int Ci, int Ho, int Wo, 
 /* Output-channel tile (128 / 64 / 32) of the LDS-DMA ring kernel (variant 1) for N x Ho x Wo output rows: the widest that divides
  * Co unless its grid would leave most of the chip idle (bench.py's kernel names). */
 int mi355_conv2d_igemm_dma_tile(int N, int Ho, int Wo, int Ci, int Co);
+int mi355_conv2d_igemm_generic_tile(int N, int Ho, int Wo, int Co);      /* ... and of the generic kernel (variant 0; fp32) */
 int mi355_conv2d_igemm_stat_rows(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW,
                                  int mul, int kmul, int off, int div, int up, int dtype);
 

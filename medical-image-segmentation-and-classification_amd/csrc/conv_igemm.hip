@@ -519,11 +519,16 @@ static int launch(const ConvArgs& a, hipStream_t s) {
   return MI355_OK;
 }
 
+// (generic kernel: the widest output-channel tile that divides Co, narrower when that grid would be at most half a round of
+//  workgroups — ResNet-18 at batch 8, fp32: 512 -> 512 @8² is 4 x 4 tiles of 128 x 128; see dma_tile_n)
+static int small_grid_tile_n(long long M, int Co);
 template <typename T, int BK>
 static int launch_bn(const ConvArgs& a, hipStream_t s) {
-  if (a.Co % 128 == 0) return launch<T, 128, BK>(a, s);
-  if (a.Co % 64 == 0) return launch<T, 64, BK>(a, s);
-  return launch<T, 32, BK>(a, s);
+  switch (small_grid_tile_n(a.M, a.Co)) {
+    case 128: return launch<T, 128, BK>(a, s);
+    case 64: return launch<T, 64, BK>(a, s);
+    default: return launch<T, 32, BK>(a, s);
+  }
 }
 
 enum IgemmVariant { IG_GENERIC = 0, IG_DMA, IG_HALO_8x32, IG_HALO_16x16, IG_STREAM1x1, IG_HALO_PP, IG_HALO_PP128, IG_WS64, IG_WS128, IG_GEMM256 };
@@ -609,6 +614,18 @@ static IgemmVariant resolve_variant(IgemmVariant v, int N, int Ho, int Wo, int C
 // Output-channel tile of the LDS-DMA ring kernel: the widest that divides Co — unless its grid leaves most of the chip idle (the
 // frozen ResNet-50 encoder's 8 x 8 and 16 x 16 layers at batch 32: M = 2048 rows x 512 channels = 64 workgroups of 128 x 128), then
 // the next narrower one (twice / four times the workgroups).  MI355_DMA_SMALLGRID=0: always the widest (A/B).
+static int small_grid_tile_n(long long M, int Co) {
+  static const int small = getenv("MI355_DMA_SMALLGRID") ? atoi(getenv("MI355_DMA_SMALLGRID")) : 1;
+  const long long rows = (M + 127) / 128;
+  int bn = Co % 128 == 0 ? 128 : (Co % 64 == 0 ? 64 : 32);
+  if (small) {
+    const int cus = device_cus();
+    if (bn == 128 && rows * (Co / 128) * 2 <= cus) bn = 64;
+    if (bn == 64 && rows * (Co / 64) * 2 <= cus) bn = 32;
+  }
+  return bn;
+}
+
 static int dma_tile_n(long long M, int Ci, int Co) {
   static const int small = getenv("MI355_DMA_SMALLGRID") ? atoi(getenv("MI355_DMA_SMALLGRID")) : 1;
   const long long rows = (M + 127) / 128;
@@ -648,6 +665,7 @@ extern "C" int mi355_conv2d_igemm_variant_n(int N, int Hi, int Wi, int Ci, int H
 
 /* output-channel tile (128 / 64 / 32) the LDS-DMA ring kernel (variant 1) runs for N x Ho x Wo rows, Ci -> Co channels */
 extern "C" int mi355_conv2d_igemm_dma_tile(int N, int Ho, int Wo, int Ci, int Co) { return dma_tile_n((long long)N * Ho * Wo, Ci, Co); }
+extern "C" int mi355_conv2d_igemm_generic_tile(int N, int Ho, int Wo, int Co) { return small_grid_tile_n((long long)N * Ho * Wo, Co); }
 
 extern "C" int mi355_conv2d_igemm_stat_rows(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH, int KW, int mul,
                                             int kmul, int off, int div, int up, int dtype) {

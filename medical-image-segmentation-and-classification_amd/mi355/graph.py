@@ -654,11 +654,11 @@ class Builder:
         per-kernel time and FLOP sums never mix two kernels under one name."""
         bn = 128 if co % 128 == 0 else (64 if co % 64 == 0 else 32)
         if self.dtype == torch.float32:
-            return f"conv_igemm_kernel<f32,{bn},16>"
+            return f"conv_igemm_kernel<f32,{lib.mi355_conv2d_igemm_generic_tile(N, Ho, Wo, co)},16>"
         v = lib.mi355_conv2d_igemm_variant_n(N, Hi, Wi, ci, Ho, Wo, co, k, k, mul, kmul, off, div, up, self.code)
         k64 = ci % 64 == 0
         if v == 0:
-            return f"conv_igemm_kernel<bf16,{bn},{64 if k64 else 32}>"
+            return f"conv_igemm_kernel<bf16,{lib.mi355_conv2d_igemm_generic_tile(N, Ho, Wo, co)},{64 if k64 else 32}>"
         if v == 1:
             bn = lib.mi355_conv2d_igemm_dma_tile(N, Ho, Wo, ci, co)      # (narrower than Co allows when the grid would be small)
             if bn == 128:

@@ -107,7 +107,10 @@ constexpr int LIN_BT = 16;      // batch rows per pass
 // y[b][o] = act(sum_i x[b][i] w[o][i] + bias[o]): a wave owns LIN_R consecutive output rows and strides them in float4s, so a
 // 16-byte piece of every batch row (L1 / L2 traffic: 16 loads) meets LIN_R weight loads instead of one — with one row per wave the
 // kernel moved 17 bytes through the L1 per weight byte and ran at 0.66 TB/s (scripts/linear_bench.py).
-constexpr int LIN_R = 4;
+#ifndef LIN_R_ROWS
+#define LIN_R_ROWS 4
+#endif
+constexpr int LIN_R = LIN_R_ROWS;
 typedef float lin_f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 lin_ldnt(const float4* p) {      // streaming 16-byte load / store of the weight matrix
   const lin_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const lin_f32x4*>(p));

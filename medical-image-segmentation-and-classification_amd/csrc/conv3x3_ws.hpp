@@ -345,12 +345,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(const ConvArgs a, co
       // this thread's first chunk of the tile: row `it` of the tile is `it` pixel rows further on (store_pending's addressing)
       T* const ptile = out + ((size_t)(n * a.Ho + y0) * a.Wo + x0 + (tid >> 3)) * a.ldo + n0 + (tid & 7) * EPC;
       if (a.accumulate) {
+        // all the old values first (the accumulators are dead here: registers to spare) — read one row at a time, every load sat
+        // behind the previous row's store to the same tensor: TH dependent round trips per tile (R2AttU_Net's first application
+        // of a recurrent block: 0.104 ms against 0.070 for the same convolution without the accumulation)
+        Vec16<T> old[NSTORE];
+#pragma unroll
+        for (int it = 0; it < NSTORE; ++it) old[it] = ld16<T>(ptile + it * row_stride);
 #pragma unroll
         for (int it = 0; it < NSTORE; ++it) {
           Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(cst_rd + it * TW * C_PITCH);
-          const Vec16<T> o = ld16<T>(ptile + it * row_stride);
 #pragma unroll
-          for (int e = 0; e < EPC; ++e) v.v[e] = from_f32<T>(to_f32<T>(v.v[e]) + to_f32<T>(o.v[e]));
+          for (int e = 0; e < EPC; ++e) v.v[e] = from_f32<T>(to_f32<T>(v.v[e]) + to_f32<T>(old[it].v[e]));
           st16<T>(ptile + it * row_stride, v);
         }
       } else {           // plain: the stores ride in the next tile's MFMA stream (store_pending), or behind the loop

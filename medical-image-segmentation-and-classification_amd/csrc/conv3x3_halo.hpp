@@ -316,17 +316,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_rw_kernel(const ConvArgs 
     }
     return;
   }
-  for (int id = tid; id < BM * CPRC; id += 256) {
-    const int row = id / CPRC, c = id - row * CPRC;
+  constexpr int NST = BM * CPRC / 256;
+  static_assert(NST * 256 == BM * CPRC, "whole store rounds");
+  auto addr = [&](int it) __attribute__((always_inline)) {
+    const int id = tid + it * 256, row = id / CPRC, c = id - row * CPRC;
     const int py = row / TW, px = row - py * TW;
-    T* p = out + ((size_t)(n * a.Ho + y0 + py) * a.Wo + x0 + px) * a.ldo + n0 + c * EPC;
-    Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(lds + row * C_PITCH + c * 16);
-    if (a.accumulate) {
-      const Vec16<T> o = ld16<T>(p);
+    return out + ((size_t)(n * a.Ho + y0 + py) * a.Wo + x0 + px) * a.ldo + n0 + c * EPC;
+  };
+  if (a.accumulate) {      // all old values first: read per round, every load sat behind the previous round's store to the same tensor
+    Vec16<T> old[NST];
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) v.v[e] = from_f32<T>(to_f32<T>(v.v[e]) + to_f32<T>(o.v[e]));
+    for (int it = 0; it < NST; ++it) old[it] = ld16<T>(addr(it));
+#pragma unroll
+    for (int it = 0; it < NST; ++it) {
+      const int id = tid + it * 256, row = id / CPRC, c = id - row * CPRC;
+      Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(lds + row * C_PITCH + c * 16);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) v.v[e] = from_f32<T>(to_f32<T>(v.v[e]) + to_f32<T>(old[it].v[e]));
+      st16<T>(addr(it), v);
     }
-    st16<T>(p, v);
+  } else {
+#pragma unroll
+    for (int it = 0; it < NST; ++it) {
+      const int id = tid + it * 256, row = id / CPRC, c = id - row * CPRC;
+      st16<T>(addr(it), *reinterpret_cast<const Vec16<T>*>(lds + row * C_PITCH + c * 16));
+    }
   }
 }
 

@@ -395,6 +395,30 @@ __global__ __launch_bounds__(512) void conv3x3_halo_pp128_kernel(const ConvArgs 
     }
     return;
   }
+#ifdef PP128_ACC_BATCH      // (A/B: all old values of the accumulate epilogue before the first store, as in the four-wave kernel)
+  constexpr int NST = BM * CPRC / 512;
+  static_assert(NST * 512 == BM * CPRC, "whole store rounds");
+  if (a.accumulate) {
+    Vec16<T> old[NST];
+#pragma unroll
+    for (int it = 0; it < NST; ++it) {
+      const int id = tid + it * 512, row = id / CPRC, c = id - row * CPRC;
+      const int py = row / TW, px = row - py * TW;
+      old[it] = ld16<T>(out + ((size_t)(n * a.Ho + y0 + py) * a.Wo + x0 + px) * a.ldo + n0 + c * EPC);
+    }
+#pragma unroll
+    for (int it = 0; it < NST; ++it) {
+      const int id = tid + it * 512, row = id / CPRC, c = id - row * CPRC;
+      const int py = row / TW, px = row - py * TW;
+      T* p = out + ((size_t)(n * a.Ho + y0 + py) * a.Wo + x0 + px) * a.ldo + n0 + c * EPC;
+      Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(lds + (row / HBM) * Cfg::C_BYTES + (row % HBM) * C_PITCH + c * 16);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) v.v[e] = from_f32<T>(to_f32<T>(v.v[e]) + to_f32<T>(old[it].v[e]));
+      st16<T>(p, v);
+    }
+    return;
+  }
+#endif
   for (int id = tid; id < BM * CPRC; id += 512) {
     const int row = id / CPRC, c = id - row * CPRC;
     const int py = row / TW, px = row - py * TW;

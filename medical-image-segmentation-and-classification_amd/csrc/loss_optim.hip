@@ -81,10 +81,23 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   double acc = 0;
   const long long n4 = n >> 2;
   const float4* g4 = reinterpret_cast<const float4*>(g);
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+  // four 16-byte loads in flight per thread, four independent double chains (one load and one dependent chain per trip ran at
+  // 0.85 TB/s: 0.165 ms for the 140 MB of Attention U-Net's gradients)
+  const long long st = (long long)gridDim.x * 256;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  double a1 = 0, a2 = 0, a3 = 0;
+  for (; i + 3 * st < n4; i += 4 * st) {
+    const float4 v0 = g4[i], v1 = g4[i + st], v2 = g4[i + 2 * st], v3 = g4[i + 3 * st];
+    acc += (double)v0.x * v0.x + (double)v0.y * v0.y + (double)v0.z * v0.z + (double)v0.w * v0.w;
+    a1 += (double)v1.x * v1.x + (double)v1.y * v1.y + (double)v1.z * v1.z + (double)v1.w * v1.w;
+    a2 += (double)v2.x * v2.x + (double)v2.y * v2.y + (double)v2.z * v2.z + (double)v2.w * v2.w;
+    a3 += (double)v3.x * v3.x + (double)v3.y * v3.y + (double)v3.z * v3.z + (double)v3.w * v3.w;
+  }
+  for (; i < n4; i += st) {
     const float4 v = g4[i];
     acc += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
   }
+  acc = (acc + a1) + (a2 + a3);
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const float v = g[(n4 << 2) + threadIdx.x];
     acc += (double)v * v;

@@ -81,8 +81,8 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   double acc = 0;
   const long long n4 = n >> 2;
   const float4* g4 = reinterpret_cast<const float4*>(g);
-  // four 16-byte loads in flight per thread, four independent double chains (one load and one dependent chain per trip ran at
-  // 0.85 TB/s: 0.165 ms for the 140 MB of Attention U-Net's gradients)
+  // four 16-byte loads in flight per thread, four independent double chains (was one load and one dependent chain per trip; the
+  // pass is a small part of the step either way — scripts/opt_time.py measures the CALL, which is bound by its host side)
   const long long st = (long long)gridDim.x * 256;
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   double a1 = 0, a2 = 0, a3 = 0;

@@ -394,6 +394,28 @@ def test_ping_pong_halo_variant_passes_the_same_cases():
     assert lib.mi355_conv2d_igemm_variant(32, 64, 96, 32, 64, 64, 3, 3, 1, 1, -1, 1, 0, code) == 2           # default: the 4-wave kernel
 
 
+def test_wide_tiles_pass_the_same_cases_with_the_small_grid_rule_off():
+    """The generic and the LDS-DMA ring kernel take a narrower output-channel tile when the widest one would launch at most half a
+    round of workgroups (csrc/conv_igemm.hip: small_grid_tile_n, dma_tile_n) — which is every small shape of this file.  The
+    128- / 64-wide instances therefore get their parity cases in a child process with MI355_DMA_SMALLGRID=0 (the switch is read
+    once per process), and the rule itself is asserted through its query functions."""
+    import os, subprocess, sys
+    if os.environ.get("MI355_DMA_SMALLGRID") == "0":
+        pytest.skip("already the child process")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
+                        "fwd or dgrad or statistics or slices or transpose"], env=dict(os.environ, MI355_DMA_SMALLGRID="0"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    # ResNet-50's layer4 at batch 32 (8 x 8 x 512 channels: 16 row tiles x 4 wide tiles = 64 workgroups) -> 32-wide tiles;
+    # AttentionUNet's 32 x 32 x 512 -> 256 gate projection at batch 32 (256 row tiles) keeps the 128-wide tile
+    assert lib.mi355_conv2d_igemm_dma_tile(32, 8, 8, 512, 512) == 32
+    assert lib.mi355_conv2d_igemm_dma_tile(32, 16, 16, 1024, 256) == 64
+    assert lib.mi355_conv2d_igemm_dma_tile(32, 32, 32, 512, 256) == 128
+    assert lib.mi355_conv2d_igemm_dma_tile(2, 8, 8, 96, 64) == 64            # (Ci % 64 != 0: no 32-wide instance)
+    assert lib.mi355_conv2d_igemm_generic_tile(8, 8, 8, 512) == 32           # ResNet-18 layer4 at batch 8 (fp32)
+    assert lib.mi355_conv2d_igemm_generic_tile(32, 256, 256, 128) == 128
+
+
 def test_128_channel_ping_pong_variant_passes_the_same_cases():
     """conv3x3_halo_pp128.hpp (16 x 32 pixels x 128 channels per 512-thread workgroup; the default from Ci = 256 up) with the
     threshold lowered to every eligible shape (MI355_HALO_PP128_MINCI=64) in a child process: forward / data gradient / statistics /

@@ -408,6 +408,73 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ x, int ldx, const T* __
   }
 }
 
+// k = 3, stride = 2, pad = 1 (the ResNet stems, ResNet.py:105): the same gather with everything that depends on k / stride / pad
+// at compile time and EVERY load issued from a clamped coordinate and masked afterwards — the generic kernel above walks up to
+// four windows x nine taps under `continue`s, i.e. up to 36 loads each branched around and waited for on the spot (0.24 ms for
+// ResNet-50's 16 x 128 x 128 x 64 stem output).  A pixel (h, w) lies in window rows h >> 1 and, when h is odd, (h + 1) >> 1.
+template <typename T>
+__global__ void maxpool3s2_bwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
+                                      T* __restrict__ dx, int lddx, int N, int H, int W, int C, int Ho, int Wo, int accumulate) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  const int cp = C / EPC;
+  const long long total = (long long)N * H * W * cp;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % cp) * EPC;
+    long long p = i / cp;
+    const int w = (int)(p % W); p /= W;
+    const int h = (int)(p % H);
+    const int n = (int)(p / H);
+    const T* xn = x + (size_t)n * H * W * ldx + c0;
+    const Vec16<T> xv = ld16<T>(xn + ((size_t)h * W + w) * ldx);
+    float g[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) g[e] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int ho = (h + a) >> 1, wo = (w + b) >> 1;
+        const bool valid = (a == 0 || (h & 1)) && (b == 0 || (w & 1)) && ho < Ho && wo < Wo;
+        const int hoc = min(ho, Ho - 1), woc = min(wo, Wo - 1);
+        Vec16<T> ov[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int hh = 2 * hoc - 1 + t / 3, ww = 2 * woc - 1 + t % 3;
+          ov[t] = ld16<T>(xn + ((size_t)min(max(hh, 0), H - 1) * W + min(max(ww, 0), W - 1)) * ldx);
+        }
+        const Vec16<T> gv = ld16<T>(dy + ((size_t)(n * Ho + hoc) * Wo + woc) * lddy + c0);
+        bool win[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) win[e] = valid;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int hh = 2 * hoc - 1 + t / 3, ww = 2 * woc - 1 + t % 3;
+          const bool consider = (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W && !(hh == h && ww == w);
+          const bool earlier = hh < h || (hh == h && ww < w);      // (first maximum in scan order: earlier ones strictly smaller)
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) {
+            const float av = to_f32<T>(xv.v[e]), bv = to_f32<T>(ov[t].v[e]);
+            win[e] = win[e] && (!consider || (earlier ? (bv < av) : (bv <= av)));
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e)
+          if (win[e]) g[e] += to_f32<T>(gv.v[e]);
+      }
+    T* o = dx + ((size_t)(n * H + h) * W + w) * lddx + c0;
+    Vec16<T> outv;
+    if (accumulate) {
+      outv = ld16<T>(o);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) outv.v[e] = from_f32<T>(to_f32<T>(outv.v[e]) + g[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) outv.v[e] = from_f32<T>(g[e]);
+    }
+    st16<T>(o, outv);
+  }
+}
+
 // k = 2, stride = 2, pad = 0 (every U-Net / VGG pool): windows do not overlap, so one thread owns one pooled
 // pixel x 16-B chunk: reads the four inputs and dy once, writes the four gradients once.
 template <typename T>
@@ -474,6 +541,13 @@ extern "C" int mi355_maxpool_bwd(const void* x, int ldx, const void* dy, int ldd
   }
   long long blocks = ((long long)N * H * W * (C / epc) + 255) / 256;
   if (blocks > 8192) blocks = 8192;
+  if (k == 3 && stride == 2 && pad == 1)
+    return dispatch_dtype(dtype, "maxpool3s2_bwd_kernel", [&](auto tag) {
+      using T = decltype(tag);
+      hipLaunchKernelGGL((maxpool3s2_bwd_kernel<T>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx, (const T*)dy, lddy, (T*)dx, lddx, N, H, W, C, Ho, Wo, accumulate);
+      MI355_LAUNCH_CHECK();
+      return (int)MI355_OK;
+    });
   return dispatch_dtype(dtype, "maxpool_bwd_kernel", [&](auto tag) {
     using T = decltype(tag);
     hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx, (const T*)dy, lddy, (T*)dx, lddx, N, H, W, C, Ho, Wo, k, stride, pad, accumulate);

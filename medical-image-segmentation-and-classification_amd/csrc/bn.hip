@@ -273,6 +273,9 @@ extern "C" int mi355_bn_act(const void* x, int ldx, const float* scale, const fl
   });
 }
 
+#ifndef BN_ACT_POOL_WGS
+#define BN_ACT_POOL_WGS 16     // workgroups per CU of the window-ordered forward apply passes (4 / 8 / 16: 5.72 / 5.81 / 5.91 TB/s, profiles/r04n_actwg.txt)
+#endif
 // ---- apply + ReLU with the following MaxPool2d(2, 2) in the same pass (AttentionUNet.py:61,89-95: every encoder level) --------
 // A thread owns one 16-byte channel chunk of one 2 x 2 pixel group: four reads of the raw convolution output, four writes of the
 // activation (the skip connection / gate / next convolution read it), one write of the pooled tensor — the separate pooling pass
@@ -335,7 +338,7 @@ extern "C" int mi355_bn_act_pool2(const void* x, int ldx, const float* scale, co
   const int epc = dtype_is_2byte(dtype) ? 8 : 4;
   MI355_CHECK_ARG(C % epc == 0, "bn_act_pool2: C=%d must be a multiple of %d", C, epc);
   long long blocks = ((long long)N * (H / 2) * (W / 2) * (C / epc) + 255) / 256;
-  if (blocks > 256 * 8) blocks = 256 * 8;
+  if (blocks > 256 * BN_ACT_POOL_WGS) blocks = 256 * BN_ACT_POOL_WGS;
   return dispatch_dtype(dtype, "bn_act_pool2", [&](auto tag) {
     using T = decltype(tag);
     hipLaunchKernelGGL((bn_act_pool2_kernel<T, false>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx, scale, shift, (T*)y, ldy,
@@ -353,7 +356,7 @@ extern "C" int mi355_bn_act_windows(const void* x, int ldx, const float* scale, 
   const int epc = dtype_is_2byte(dtype) ? 8 : 4;
   MI355_CHECK_ARG(C % epc == 0, "bn_act_windows: C=%d must be a multiple of %d", C, epc);
   long long blocks = ((long long)N * (H / 2) * (W / 2) * (C / epc) + 255) / 256;
-  if (blocks > 256 * 8) blocks = 256 * 8;
+  if (blocks > 256 * BN_ACT_POOL_WGS) blocks = 256 * BN_ACT_POOL_WGS;
   return dispatch_dtype(dtype, "bn_act_windows", [&](auto tag) {
     using T = decltype(tag);
     if (res)

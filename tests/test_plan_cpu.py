@@ -205,6 +205,35 @@ def test_recurrent_convs_get_one_weight_gradient_launch(monkeypatch):
     assert n_reduce_single - n_reduce_multi == 5 * len(multis)
 
 
+def test_recurrent_block_input_gradient_is_summed_once(monkeypatch):
+    """R2AttU_Net (t = 5: six applications per recurrent block, five of which add the block input, R2AttU_Net.py:41-44): with
+    DEFER_POST every block's backward has ONE mi355_bn_bwd_apply_post4 carrying four earlier incoming gradients of the pitch of the
+    current one, and no plain apply pass of a recurrent application carries a post-activation operand; without it there is no post4
+    launch and five passes per block read-modify-write the operand's gradient.  ABI arity checked by bind()."""
+    from models.segmentation_models.R2AttU_Net import R2AttU_Net
+
+    def plan_of(defer):
+        monkeypatch.setattr(graph, "DEFER_POST", defer)
+        net = R2AttU_Net().train()
+        net.engine.flatten()
+        plan = net.engine.plan_for((1, 3, 32, 32), True, True, torch.bfloat16)
+        plan.bind(0)
+        return plan
+
+    on, off = plan_of(True), plan_of(False)
+    post4 = [l for l in on.bwd if l.name == "mi355_bn_bwd_apply_post4"]
+    assert len(post4) == 18                                   # 9 RRCNN blocks x 2 recurrent blocks
+    for l in post4:
+        ex = l.args[17:21]
+        assert all(e is not None for e in ex) and len({id(e) for e in ex} | {id(l.args[0])}) == 5      # four earlier gradients + this one
+        assert all(e.ld == l.args[21] for e in ex) and l.args[14] is not None                          # one pitch; the operand's gradient
+    plain_on = [l for l in on.bwd if l.name == "mi355_bn_bwd_apply"]
+    plain_off = [l for l in off.bwd if l.name == "mi355_bn_bwd_apply"]
+    assert not any(l.name == "mi355_bn_bwd_apply_post4" for l in off.bwd)
+    with_post = lambda ls: sum(l.args[16] is not None for l in ls)                                       # dpost argument
+    assert with_post(plain_off) - with_post(plain_on) == 18 * 5 and len(plain_off) == len(plain_on) + 18
+
+
 @pytest.mark.parametrize("name", ["ResNetUnet", "AttentionUNet", "R2AttU_Net", "ResNet50", "VGG16_BN"])
 def test_slab_workspace_is_owned_by_one_stream(name):
     """The split-K slab workspace Ws('bytes') is shared by every weight-gradient launch of a plan; the side stream

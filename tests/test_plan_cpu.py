@@ -205,6 +205,18 @@ def test_recurrent_convs_get_one_weight_gradient_launch(monkeypatch):
     assert n_reduce_single - n_reduce_multi == 5 * len(multis)
 
 
+def test_small_grid_tile_rule():
+    """csrc/conv_igemm.hip small_grid_tile_n / dma_tile_n (host code; 256 CUs assumed without a device): the widest output-channel
+    tile that divides Co, narrower when that grid would be at most half a round of workgroups."""
+    assert lib.mi355_conv2d_igemm_dma_tile(32, 8, 8, 512, 512) == 32            # ResNet-50 layer4 at batch 32: 16 x 4 wide tiles
+    assert lib.mi355_conv2d_igemm_dma_tile(32, 16, 16, 1024, 256) == 64
+    assert lib.mi355_conv2d_igemm_dma_tile(32, 32, 32, 512, 256) == 128         # 256 row tiles: the wide tile stays
+    assert lib.mi355_conv2d_igemm_dma_tile(2, 8, 8, 96, 64) == 64               # Ci % 64 != 0: no 32-wide instance
+    assert lib.mi355_conv2d_igemm_generic_tile(8, 8, 8, 512) == 32              # ResNet-18 layer4 at batch 8
+    assert lib.mi355_conv2d_igemm_generic_tile(32, 256, 256, 128) == 128
+    assert lib.mi355_conv2d_igemm_generic_tile(2, 8, 8, 96) == 32               # 96 channels: 32-wide tiles anyway
+
+
 def test_recurrent_block_input_gradient_is_summed_once(monkeypatch):
     """R2AttU_Net (t = 5: six applications per recurrent block, five of which add the block input, R2AttU_Net.py:41-44): with
     DEFER_POST every block's backward has ONE mi355_bn_bwd_apply_post4 carrying four earlier incoming gradients of the pitch of the
